@@ -1,0 +1,145 @@
+/*
+ * rex.h -- C-ABI of the MI355X-native batched domain-randomised locomotion simulator.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json:north_star:
+ * the per-instance forward-dynamics step() and the reset()-time xi sampling of the
+ * random_envs environments, batched one environment per GPU lane.
+ *
+ * The reference (gabrieletiboni/random-envs) has no FFI of its own: its native boundary is
+ * mujoco-py's Cython binding (MjSim.step / forward / reset / get_state / set_state and raw
+ * views into MjModel / MjData).  Each entry point below cites the reference interface it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no C++ / torch types; every pointer marked [dev] is a caller-owned DEVICE
+ *     pointer (e.g. torch.Tensor.data_ptr()), every pointer marked [host] is host memory.
+ *   - all calls return 0 on success or a negative rex_status; rex_last_error() gives the
+ *     message (thread-local).  No C++ exception crosses this boundary.  (The reference raises
+ *     Python exceptions, or drops into pdb on MujocoException: jinja_mujoco_env.py:153-164.)
+ *   - kernels are enqueued asynchronously on the caller's HIP stream (`stream`, a hipStream_t
+ *     passed as void*, NULL = default stream).  No allocation or synchronisation in
+ *     rex_step / rex_reset.
+ *   - internal state is SoA [field][env]; I/O buffers are SoA too: obs is [obs_dim][batch],
+ *     action is [act_dim][batch], xi is [task_dim][batch] (a torch [batch, dim] view is the
+ *     zero-copy transpose).  reward is float[batch], done / truncated are uint8[batch].
+ *   - a handle is bound to one device; calls on one handle are not re-entrant.
+ */
+#ifndef REX_H_
+#define REX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rex_env rex_t;
+
+/* env_kind: one per kinematic chain of the reference. */
+enum rex_env_kind {
+  REX_CARTPOLE    = 0, /* random_envs/random_cartpole.py:19            */
+  REX_HOPPER      = 1, /* random_envs/jinja/random_hopper.py:16        */
+  REX_HALFCHEETAH = 2, /* random_envs/jinja/random_half_cheetah.py:17  */
+  REX_WALKER2D    = 3, /* random_envs/jinja/random_walker2d.py:19      */
+  REX_HUMANOID    = 4  /* random_envs/jinja/random_humanoid.py:27      */
+};
+
+/* dr_type of RandomEnv.set_dr_distribution (random_envs/random_env.py:72-90). */
+enum rex_dr_type {
+  REX_DR_NONE         = 0,
+  REX_DR_UNIFORM      = 1, /* params = [lo0,hi0,lo1,hi1,...]     random_env.py:102-107 */
+  REX_DR_TRUNCNORM    = 2, /* params = [mean0,std0,...]          random_env.py:109-114 */
+  REX_DR_GAUSSIAN     = 3, /* params = [mean0,std0,...]          random_env.py:116-121 */
+  REX_DR_FULLGAUSSIAN = 4  /* params = [mean(d), chol(cov)(d*d, row-major lower), lo(d), hi(d)]
+                              random_env.py:123-127,192-198,205-220 */
+};
+
+enum rex_status {
+  REX_OK            =  0,
+  REX_ERR_ARG       = -1, /* bad argument (unknown env kind / dr type / sizes)   */
+  REX_ERR_HIP       = -2, /* a HIP runtime call failed                           */
+  REX_ERR_STATE     = -3, /* call sequence error (e.g. sampling before set_dr)   */
+  REX_ERR_UNSUPPORTED = -4
+};
+
+/* Static description of an env kind (dims of SURVEY.md section 8 table). */
+typedef struct rex_dims {
+  int nq, nv, act_dim, obs_dim, task_dim;
+  int frame_skip;
+  int max_episode_steps; /* 500 for all 13 ids, e.g. random_hopper.py:155-166 */
+  int discrete_action;   /* 1 for CartPole (Discrete(2), random_cartpole.py:96) */
+  float dt;              /* model timestep * frame_skip, jinja_mujoco_env.py:166-168 */
+  float act_low, act_high; /* actuator_ctrlrange, jinja_mujoco_env.py:99-103 */
+} rex_dims;
+
+int rex_get_dims(int env_kind, rex_dims* out);
+
+/* Replaces MujocoEnv.__init__ / build_model (jinja_mujoco_env.py:43-97): load_model_from_xml +
+ * MjSim for `batch` environments at once.  `env_offset` is the global index of this handle's
+ * first env: RNG streams are keyed by the GLOBAL env index so results do not depend on how a
+ * batch is sharded over GPUs.  `variant` 0 = regular id, 1 = "Unmodeled" id. */
+int rex_create(int env_kind, int variant, int64_t batch, int device_id, uint64_t seed,
+               int64_t env_offset, rex_t** out);
+int rex_destroy(rex_t* h);
+
+/* RandomEnv.set_dr_distribution (random_env.py:72-127).  `params` [host] layout per rex_dr_type;
+ * `lower_bounds` [host, task_dim] = get_task_lower_bound(i) (e.g. random_hopper.py:60-72), used by
+ * the truncnorm resampling rule (random_env.py:153-171). May be NULL for the other types. */
+int rex_set_dr(rex_t* h, int dr_type, const float* params, int n_params, const float* lower_bounds);
+/* RandomEnv.set_dr_training (random_env.py:41-46). */
+int rex_set_dr_training(rex_t* h, int flag);
+/* set_endless (random_env.py:51-60); `noisy` ctor kwarg + noise_level (random_hopper.py:17-28);
+ * noise_var < 0 keeps the env's reference default. */
+int rex_set_flags(rex_t* h, int endless, int noisy, float noise_var);
+/* auto-reset of finished lanes inside rex_step (SB3 VecEnv convention used by the reference's
+ * downstream, README.md:68); time-limit truncation at max_episode_steps (gym TimeLimit). */
+int rex_set_autoreset(rex_t* h, int autoreset, int time_limit);
+/* seed(): MujocoEnv.seed (jinja_mujoco_env.py:109-111). Re-keys the Philox streams. */
+int rex_seed(rex_t* h, uint64_t seed);
+
+/* MujocoEnv.reset + reset_model (jinja_mujoco_env.py:141-144, random_hopper.py:112-120):
+ * lanes with mask[i]!=0 (all lanes if mask==NULL) get qpos0/qvel0 + init noise, a fresh xi when
+ * dr_training is on, and their observation written to obs_out [dev, obs_dim*batch] (may be NULL). */
+int rex_reset(rex_t* h, const uint8_t* mask, float* obs_out, void* stream);
+
+/* step(): RandomHopperEnv.step etc. (random_hopper.py:83-98) = do_simulation
+ * (jinja_mujoco_env.py:170-173: ctrl <- a; frame_skip x sim.step()) + reward + done + _get_obs.
+ * action [dev]: float[act_dim*batch] (CartPole: int32[batch], values 0/1).
+ * Optional outputs (NULL to skip): truncated_out (TimeLimit.truncated), terminal_obs_out
+ * (observation before auto-reset). */
+int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
+             uint8_t* truncated_out, float* terminal_obs_out, void* stream);
+
+/* get_sim_state / set_sim_state (random_hopper.py:148-152), MujocoEnv.set_state
+ * (jinja_mujoco_env.py:146-154), state_vector (:231-235). qpos [dev, nq*batch], qvel [dev, nv*batch].
+ * CartPole: qpos = (x, theta), qvel = (x_dot, theta_dot). */
+int rex_get_state(rex_t* h, float* qpos, float* qvel, void* stream);
+int rex_set_state(rex_t* h, const float* qpos, const float* qvel, void* stream);
+/* get_task / set_task (random_hopper.py:75-80 etc.). xi [dev, task_dim*batch]. */
+int rex_get_task(rex_t* h, float* xi, void* stream);
+int rex_set_task(rex_t* h, const float* xi, void* stream);
+/* set_random_task (random_env.py:37-39) for the masked lanes, without touching their state. */
+int rex_set_random_task(rex_t* h, const uint8_t* mask, void* stream);
+/* current observation of every lane (_get_obs, random_hopper.py:100-110), without noise. */
+int rex_get_obs(rex_t* h, float* obs_out, void* stream);
+
+/* number of env-steps executed by this handle (host counter; the only quantity the multi-GPU
+ * path reduces across ranks). */
+int64_t rex_step_count(const rex_t* h);
+/* device-side diagnostics accumulated since creation: [0] lanes that went non-finite,
+ * [1] gaussian-DR draws that failed the reference's 3-attempt rule (random_env.py:173-190),
+ * [2] constraint solves that hit the iteration cap. Copies 4 int64 to `out` [host]; synchronises. */
+int rex_get_counters(rex_t* h, int64_t* out);
+
+/* duration in ms of the last `n` rex_step kernel launches measured with HIP events on the
+ * launch stream (enabled by rex_enable_timing); returns the number of samples written. */
+int rex_enable_timing(rex_t* h, int enable);
+int rex_read_timing(rex_t* h, float* ms_out, int max_n);
+
+const char* rex_last_error(void);
+const char* rex_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REX_H_ */

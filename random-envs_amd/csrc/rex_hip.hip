@@ -1,0 +1,667 @@
+// rex_hip.hip -- HIP kernels (gfx950 / MI355X) + the C-ABI of include/rex.h.
+//
+// Execution model: ONE ENVIRONMENT PER LANE, 64-lane workgroups (one wavefront each) so a batch
+// of B envs is B/64 independent waves spread over the 256 CUs.  State is SoA in HBM
+// (qpos[nq][B], qvel[nv][B], xi[dim][B], ...): lane i touches element i of every row, so every
+// global access of a wave is one contiguous 256-byte segment.  The whole per-env solve
+// (composite-inertia M, L^T D L, pyramidal contact rows, Newton) lives in VGPRs
+// (planar_engine.hpp); hopper / half-cheetah model constants arrive as kernel arguments
+// (scalar registers), walker2d's per-env geometry as SoA rows.  No LDS, no MFMA: these are
+// tiny per-instance solves, not dense contractions.
+//
+// reset()-time xi sampling and init-state noise use rocRAND's Philox4x32-10 device API with
+// subsequence = GLOBAL env index (handle env_offset + lane) and offset = f(episode, t): results
+// do not depend on how a batch is sharded over GPUs and no RNG state is stored.
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rex.h"
+#include "planar_model.hpp"
+
+using namespace rex;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIP_TRY(x)                                                                            \
+  do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(REX_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* rex_last_error(void) { return g_err; }
+extern "C" const char* rex_version(void) { return "rex-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------
+// DR distribution block (device-visible copy of RandomEnv's min/max/mean/stdev/cov state,
+// random_env.py:102-127)
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_XI = 32;
+struct DRParams {
+  int type;                 // rex_dr_type
+  int dim;
+  float a[MAX_XI];          // uniform: lo   | truncnorm/gaussian: mean | fullgaussian: mean (normalised space)
+  float b[MAX_XI];          // uniform: hi   | truncnorm/gaussian: std
+  float lower[MAX_XI];      // get_task_lower_bound(i)
+  float lo[MAX_XI], hi[MAX_XI];   // fullgaussian: search bounds for denormalisation
+  float chol[MAX_XI * MAX_XI];    // fullgaussian: lower Cholesky factor of cov, row-major
+};
+
+constexpr unsigned long long EP_STRIDE = 1ull << 16;   // Philox offsets per episode
+constexpr unsigned long long STEP_BASE = 512, STEP_STRIDE = 64;
+
+// truncated standard normal on [-2, 2] by inverse CDF (the method scipy.stats.truncnorm.rvs uses)
+__device__ __forceinline__ float truncnorm2(float u) {
+  const float Fa = 0.022750131948179195f, Fb = 0.9772498680518208f;   // Phi(-2), Phi(2)
+  float p = Fa + u * (Fb - Fa);
+  float x = normcdfinvf(p);
+  return fminf(fmaxf(x, -2.0f), 2.0f);
+}
+
+// RandomEnv.sample_task (random_env.py:148-203), one lane = one env.
+template <int NXI>
+__device__ void sample_task(const DRParams& dr, rocrand_state_philox4x32_10* st, float (&xi)[NXI],
+                            unsigned long long* counters) {
+  if (dr.type == REX_DR_UNIFORM) {           // :150-151  U(min, max) per dim
+#pragma unroll
+    for (int k = 0; k < NXI; k++) { float u = rocrand_uniform(st); xi[k] = dr.a[k] + (dr.b[k] - dr.a[k]) * (1.0f - u); }
+  } else if (dr.type == REX_DR_TRUNCNORM) {  // :153-171 (intended semantics; the reference raises NameError)
+#pragma unroll
+    for (int k = 0; k < NXI; k++) {
+      float lb = dr.lower[k];
+      float obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(st));
+      // `attempts` 1,2 keep a redraw; the third redraw is overwritten by lower_bound (:162-167)
+      for (int att = 0; att < 2 && obs < lb; att++) obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(st));
+      if (obs < lb) obs = lb;
+      xi[k] = obs;
+    }
+  } else if (dr.type == REX_DR_GAUSSIAN) {   // :173-190: redraw while < 0.1, raise after the 3rd failure
+#pragma unroll
+    for (int k = 0; k < NXI; k++) {
+      float obs = dr.a[k] + dr.b[k] * rocrand_normal(st);
+      for (int att = 0; att < 2 && obs < 0.1f; att++) obs = dr.a[k] + dr.b[k] * rocrand_normal(st);
+      if (obs < 0.1f) { obs = 0.1f; atomicAdd(counters + 1, 1ull); }   // a device lane cannot raise: clamp + count
+      xi[k] = obs;
+    }
+  } else if (dr.type == REX_DR_FULLGAUSSIAN) {  // :192-198: MVN in normalised [0,4]^d, clip, denormalise (:205-220)
+    float z[NXI];
+#pragma unroll
+    for (int k = 0; k < NXI; k++) z[k] = rocrand_normal(st);
+#pragma unroll
+    for (int k = 0; k < NXI; k++) {
+      float s = dr.a[k];
+#pragma unroll
+      for (int j = 0; j <= k; j++) s += dr.chol[k * MAX_XI + j] * z[j];
+      s = fminf(fmaxf(s, 0.0f), 4.0f);
+      xi[k] = s * (dr.hi[k] - dr.lo[k]) * 0.25f + dr.lo[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// device-side state of one handle
+// ------------------------------------------------------------------------------------------
+struct DevState {
+  float* qpos; float* qvel; float* xi;     // SoA rows of length B
+  float* geom;                             // walker2d: per-env PlanarGeom rows [NGEOMF][B]; else null
+  int* t; unsigned* episode; unsigned char* done;
+  unsigned long long* counters;            // [4]
+  long long B, env_offset;
+  unsigned long long seed;
+};
+
+struct StepFlags {
+  int endless, noisy, time_limit, max_steps;
+  float noise_std;
+};
+
+// ------------------------------------------------------------------------------------------
+// CartPole (random_envs/random_cartpole.py:172-229).  qpos = (x, theta), qvel = (x_dot, theta_dot).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) cartpole_step_kernel(DevState s, StepFlags fl, const int* __restrict__ action,
+                                                           float* __restrict__ obs, float* __restrict__ reward,
+                                                           unsigned char* __restrict__ done_out, unsigned char* __restrict__ trunc_out,
+                                                           float* __restrict__ term_obs) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  const long long B = s.B;
+  float x = s.qpos[i], th = s.qpos[B + i], xd = s.qvel[i], thd = s.qvel[B + i];
+  float g = s.xi[i], mc = s.xi[B + i], mp = s.xi[2 * B + i], l = s.xi[3 * B + i];
+  float total = mp + mc;                                  // set_task :166
+  const float pml = 0.1f * 0.5f;                          // :79, not refreshed by set_task
+  float force = action[i] == 1 ? 10.0f : -10.0f;          // :80,178
+  float st, ct; sincosf(th, &st, &ct);
+  float temp = (force + pml * thd * thd * st) / total;    // :184
+  float thacc = (g * st - ct * temp) / (l * (4.0f / 3.0f - mp * ct * ct / total));   // :185
+  float xacc = temp - pml * thacc * ct / total;           // :186
+  const float tau = 0.02f;
+  x = x + tau * xd; xd = xd + tau * xacc; th = th + tau * thd; thd = thd + tau * thacc;   // :188-192
+  s.qpos[i] = x; s.qpos[B + i] = th; s.qvel[i] = xd; s.qvel[B + i] = thd;
+  const float th_thr = 12.0f * 2.0f * 3.14159265358979323846f / 360.0f, x_thr = 2.4f;   // :84-85
+  bool was_done = s.done[i] != 0;                          // steps_beyond_done bookkeeping :208-222
+  bool dn = (x < -x_thr) || (x > x_thr) || (th < -th_thr) || (th > th_thr);
+  float r = (!dn) ? 1.0f : (was_done ? 0.0f : 1.0f);
+  int t = s.t[i] + 1; s.t[i] = t;
+  bool trunc = fl.time_limit && t >= fl.max_steps && !dn;
+  bool d = dn || trunc;
+  s.done[i] = (unsigned char)((dn || was_done) ? 1 : 0) | (unsigned char)(d ? 2 : 0);
+  obs[i] = x; obs[B + i] = xd; obs[2 * B + i] = th; obs[3 * B + i] = thd;   // np.array(self.state) :224
+  if (term_obs) { term_obs[i] = x; term_obs[B + i] = xd; term_obs[2 * B + i] = th; term_obs[3 * B + i] = thd; }
+  reward[i] = r; done_out[i] = d ? 1 : 0;
+  if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+}
+
+// reset(): state ~ U(-0.05, 0.05)^4 (random_cartpole.py:226-229). `resample` = set_random_task.
+__global__ void __launch_bounds__(64) cartpole_reset_kernel(DevState s, DRParams dr, int resample, int reset_state,
+                                                            const unsigned char* __restrict__ mask, int mask_bit,
+                                                            float* __restrict__ obs) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  if (mask && !(mask[i] & mask_bit)) return;
+  const long long B = s.B;
+  unsigned ep = s.episode[i] + 1; s.episode[i] = ep;
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
+  if (reset_state) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = -0.05f + 0.1f * (1.0f - rocrand_uniform(&st));
+    s.qpos[i] = v[0]; s.qvel[i] = v[1]; s.qpos[B + i] = v[2]; s.qvel[B + i] = v[3];
+    s.t[i] = 0; s.done[i] = 0;
+    if (obs) { obs[i] = v[0]; obs[B + i] = v[1]; obs[2 * B + i] = v[2]; obs[3 * B + i] = v[3]; }
+  }
+  if (resample && dr.type != REX_DR_NONE) {
+    float xi[4]; sample_task<4>(dr, &st, xi, s.counters);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.xi[k * B + i] = xi[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// planar MuJoCo-style envs
+// ------------------------------------------------------------------------------------------
+template <class S> constexpr int geom_floats() { return sizeof(PlanarGeom<float, S>) / sizeof(float); }
+
+template <class S>
+__device__ __forceinline__ void load_geom(const DevState& s, long long i, const PlanarGeom<float, S>& uniform,
+                                          PlanarGeom<float, S>& G) {
+  if constexpr (S::KIND == 3) {   // walker2d: geometry is a function of the xi lengths
+    float* dst = reinterpret_cast<float*>(&G);
+    constexpr int N = geom_floats<S>();
+#pragma unroll
+    for (int k = 0; k < N; k++) dst[k] = s.geom[(long long)k * s.B + i];
+  } else {
+    G = uniform;
+  }
+}
+
+// observation: concat(qpos[1:], qvel) (random_hopper.py:100-110, random_half_cheetah.py:112-121,
+// random_walker2d.py:133-142) + optional N(0, noise_var)
+template <class S>
+__device__ __forceinline__ void write_obs(const float (&q)[S::NV], const float (&v)[S::NV], float* __restrict__ obs,
+                                          long long B, long long i, bool noisy, float noise_std,
+                                          rocrand_state_philox4x32_10* st) {
+  static_for<0, S::NOBS>([&](auto KK) {
+    constexpr int k = KK;
+    float o = k < S::NV - 1 ? q[k + 1] : v[k - (S::NV - 1)];
+    if (noisy) o += noise_std * rocrand_normal(st);
+    obs[(long long)k * B + i] = o;
+  });
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
+                                                         SolParams<float> sp, const float* __restrict__ action,
+                                                         float* __restrict__ obs, float* __restrict__ reward,
+                                                         unsigned char* __restrict__ done_out,
+                                                         unsigned char* __restrict__ trunc_out, float* __restrict__ term_obs) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  const long long B = s.B;
+  float q[S::NV], v[S::NV], ctrl[S::NU], xi[S::NXI];
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = s.qpos[(long long)k * B + i]; v[k] = s.qvel[(long long)k * B + i]; });
+  static_for<0, S::NU>([&](auto KK) { constexpr int k = KK; ctrl[k] = action[(long long)k * B + i]; });
+  static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; xi[k] = s.xi[(long long)k * B + i]; });
+  PlanarGeom<float, S> G; load_geom<S>(s, i, ugeom, G);
+  LaneParams<float, S> P; lane_params(S{}, xi, P);
+  // the dynamics are invariant to the root x translation: integrate the step from x = 0 so the
+  // forward-progress reward (posafter - posbefore)/dt keeps full fp32 resolution far from the origin
+  const float x_before = q[0];
+  q[0] = 0.0f;
+  bool capped = false;
+#pragma unroll 1
+  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S>(q, v, ctrl, G, P, sp);   // do_simulation, jinja_mujoco_env.py:170-173
+  const float dx = q[0];
+  q[0] = x_before + dx;
+  // reward / done
+  float asq = 0.0f;
+  static_for<0, S::NU>([&](auto KK) { asq += ctrl[KK] * ctrl[KK]; });
+  const float dt = float(S::TIMESTEP * S::FRAME_SKIP);
+  float r = dx / dt + S::ALIVE - S::CTRL_COST * asq;
+  bool finite = true;
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; finite = finite && isfinite(q[k]) && isfinite(v[k]); });
+  bool dn = false;
+  if constexpr (S::KIND == 1) {          // random_hopper.py:92
+    bool small = true;
+    static_for<2, S::NV>([&](auto KK) { constexpr int k = KK; small = small && fabsf(q[k]) < 100.0f; });
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; small = small && fabsf(v[k]) < 100.0f; });
+    dn = !(finite && small && q[1] > 0.7f && fabsf(q[2]) < 0.2f);
+  } else if constexpr (S::KIND == 3) {   // random_walker2d.py:124-125
+    dn = !(q[1] > 0.8f && q[1] < 2.0f && q[2] > -1.0f && q[2] < 1.0f);
+  } else {                               // random_half_cheetah.py:108
+    dn = false;
+  }
+  if (fl.endless) dn = false;            // random_hopper.py:95-96
+  if (!finite) atomicAdd(s.counters + 0, 1ull);
+  if (capped && threadIdx.x == 0) atomicAdd(s.counters + 2, 1ull);
+  int t = s.t[i] + 1; s.t[i] = t;
+  bool trunc = fl.time_limit && t >= fl.max_steps && !dn;     // gym TimeLimit
+  bool d = dn || trunc;
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; s.qpos[(long long)k * B + i] = q[k]; s.qvel[(long long)k * B + i] = v[k]; });
+  s.done[i] = d ? 2 : 0;
+  rocrand_state_philox4x32_10 st;
+  if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
+                             (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
+  write_obs<S>(q, v, obs, B, i, fl.noisy != 0, fl.noise_std, &st);
+  if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; term_obs[(long long)k * B + i] = obs[(long long)k * B + i]; });
+  reward[i] = r; done_out[i] = d ? 1 : 0;
+  if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+}
+
+// reset_model (random_hopper.py:112-120, random_half_cheetah.py:123-131, random_walker2d.py:144-153)
+// + set_random_task (random_env.py:37-39) for the masked lanes.
+template <class S>
+__global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
+                                                          const unsigned char* __restrict__ mask, int mask_bit,
+                                                          float* __restrict__ obs) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  if (mask && !(mask[i] & mask_bit)) return;
+  const long long B = s.B;
+  unsigned ep = s.episode[i] + 1; s.episode[i] = ep;
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
+  if (reset_state) {
+    float q[S::NV], v[S::NV];
+    const float c = S::INIT_NOISE;
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK;
+      q[k] = c * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);            // init_qpos + U(-c, c)
+      if constexpr (S::KIND == 2) v[k] = 0.1f * rocrand_normal(&st);       // random_half_cheetah.py:125
+      else v[k] = c * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
+    });
+    if constexpr (S::KIND != 2) q[1] += 1.25f;                             // init_qpos[1] = 1.25 (ref, hopper.xml:30)
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; s.qpos[(long long)k * B + i] = q[k]; s.qvel[(long long)k * B + i] = v[k]; });
+    s.t[i] = 0; s.done[i] = 0;
+    if (obs) {
+      rocrand_state_philox4x32_10 st2;
+      if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + STEP_BASE, &st2);
+      write_obs<S>(q, v, obs, B, i, fl.noisy != 0, fl.noise_std, &st2);
+    }
+  }
+  if (resample && dr.type != REX_DR_NONE) {
+    rocrand_state_philox4x32_10 st3;   // separate stream region so the xi draw does not depend on reset_state
+    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, &st3);
+    float xi[S::NXI]; sample_task<S::NXI>(dr, &st3, xi, s.counters);
+    static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; s.xi[(long long)k * B + i] = xi[k]; });
+  }
+}
+
+// walker2d: re-derive the per-env model constants from the xi lengths for the masked lanes
+// (replaces build_model() inside RandomWalker2dEnv.set_task, random_walker2d.py:106-113).
+__global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit) {
+  using S = Walker2dSpec;
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  if (mask && !(mask[i] & mask_bit)) return;
+  double size[4];
+  for (int k = 0; k < 4; k++) size[k] = (double)s.xi[(long long)(7 + k) * s.B + i];
+  PlanarGeom<double, S> G; SolParams<double> sp; double nominal[S::NB];
+  derive_model<double, S>(size, G, nominal, sp);
+  const double* src = reinterpret_cast<const double*>(&G);
+  constexpr int N = geom_floats<S>();
+  for (int k = 0; k < N; k++) s.geom[(long long)k * s.B + i] = (float)src[k];
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) planar_obs_kernel(DevState s, float* __restrict__ obs) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  float q[S::NV], v[S::NV];
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = s.qpos[(long long)k * s.B + i]; v[k] = s.qvel[(long long)k * s.B + i]; });
+  write_obs<S>(q, v, obs, s.B, i, false, 0.0f, nullptr);
+}
+__global__ void __launch_bounds__(64) cartpole_obs_kernel(DevState s, float* __restrict__ obs) {
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= s.B) return;
+  const long long B = s.B;
+  obs[i] = s.qpos[i]; obs[B + i] = s.qvel[i]; obs[2 * B + i] = s.qpos[B + i]; obs[3 * B + i] = s.qvel[B + i];
+}
+__global__ void fill_rows_kernel(float* dst, const float* vals, int nrows, long long B) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  for (int k = 0; k < nrows; k++) dst[(long long)k * B + i] = vals[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side handle
+// ------------------------------------------------------------------------------------------
+struct rex_env {
+  int kind = 0, variant = 0, device = 0;
+  long long B = 0, env_offset = 0;
+  unsigned long long seed = 0;
+  rex_dims dims{};
+  DevState dev{};
+  DRParams dr{};
+  StepFlags flags{};
+  int dr_training = 0, autoreset = 1;
+  int64_t step_count = 0;
+  // host-derived constants
+  PlanarGeom<float, HopperSpec> g_hopper{};
+  PlanarGeom<float, HalfCheetahSpec> g_cheetah{};
+  PlanarGeom<float, Walker2dSpec> g_walker{};
+  SolParams<float> sp{};
+  float nominal_xi[MAX_XI] = {0};
+  float* d_scratch = nullptr;   // MAX_XI floats
+  // timing
+  int timing = 0;
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t ev_n = 0;
+};
+
+static int fill_dims(int kind, rex_dims* d) {
+  memset(d, 0, sizeof *d);
+  d->max_episode_steps = 500;                 // every gym.envs.register call, e.g. random_hopper.py:155-166
+  switch (kind) {
+    case REX_CARTPOLE:    d->nq = 2; d->nv = 2; d->act_dim = 1; d->obs_dim = 4; d->task_dim = 4; d->frame_skip = 1;
+                          d->discrete_action = 1; d->dt = 0.02f; d->act_low = 0; d->act_high = 1; return 0;
+    case REX_HOPPER:      d->nq = 6; d->nv = 6; d->act_dim = 3; d->obs_dim = 11; d->task_dim = 4; d->frame_skip = 4;
+                          d->dt = 0.008f; d->act_low = -1; d->act_high = 1; return 0;
+    case REX_HALFCHEETAH: d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 8; d->frame_skip = 5;
+                          d->dt = 0.05f; d->act_low = -1; d->act_high = 1; return 0;
+    case REX_WALKER2D:    d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 13; d->frame_skip = 4;
+                          d->dt = 0.008f; d->act_low = -1; d->act_high = 1; return 0;
+    default: return -1;
+  }
+}
+
+extern "C" int rex_get_dims(int env_kind, rex_dims* out) {
+  if (!out) return set_err(REX_ERR_ARG, "rex_get_dims: null out");
+  if (env_kind == REX_HUMANOID) return set_err(REX_ERR_UNSUPPORTED, "humanoid kernel not built yet");
+  if (fill_dims(env_kind, out)) return set_err(REX_ERR_ARG, "unknown env kind %d", env_kind);
+  return REX_OK;
+}
+
+template <class T, class S>
+static void to_float_geom(const PlanarGeom<double, S>& g, PlanarGeom<float, S>& o) {
+  const double* src = reinterpret_cast<const double*>(&g); float* dst = reinterpret_cast<float*>(&o);
+  for (int k = 0; k < geom_floats<S>(); k++) dst[k] = (float)src[k];
+}
+static void sp_to_float(const SolParams<double>& a, SolParams<float>& b) {
+  b.con_K = (float)a.con_K; b.con_B = (float)a.con_B; b.con_dmin = (float)a.con_dmin; b.con_dmax = (float)a.con_dmax;
+  b.con_width = (float)a.con_width; b.con_margin = (float)a.con_margin; b.lim_K = (float)a.lim_K; b.lim_B = (float)a.lim_B;
+  b.lim_dmin = (float)a.lim_dmin; b.lim_dmax = (float)a.lim_dmax; b.lim_width = (float)a.lim_width; b.meaninertia = (float)a.meaninertia;
+}
+
+template <class S>
+static void host_derive(rex_env* h, PlanarGeom<float, S>& out) {
+  PlanarGeom<double, S> G; SolParams<double> sp; double nominal[S::NB]; double size[8];
+  for (int k = 0; k < S::NSIZE; k++) size[k] = S::default_size[k];
+  derive_model<double, S>(size, G, nominal, sp);
+  to_float_geom<double, S>(G, out); sp_to_float(sp, h->sp);
+  for (int b = 0; b < S::NB; b++) h->nominal_xi[b] = (float)nominal[b];
+}
+
+static unsigned grid_for(long long B) { return (unsigned)((B + 63) / 64); }
+
+static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st) {
+  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h->B)), dim3(64), 0, st, h->dev, mask, bit);
+  HIP_TRY(hipGetLastError());
+  return REX_OK;
+}
+
+extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_id, uint64_t seed, int64_t env_offset,
+                          rex_t** out) {
+  if (!out) return set_err(REX_ERR_ARG, "rex_create: null out");
+  if (batch <= 0) return set_err(REX_ERR_ARG, "rex_create: batch must be > 0 (got %lld)", (long long)batch);
+  if (env_kind == REX_HUMANOID) return set_err(REX_ERR_UNSUPPORTED, "humanoid kernel not built yet");
+  if (variant != 0) return set_err(REX_ERR_UNSUPPORTED, "unmodeled variants not built yet");
+  rex_dims dims;
+  if (fill_dims(env_kind, &dims)) return set_err(REX_ERR_ARG, "unknown env kind %d", env_kind);
+  HIP_TRY(hipSetDevice(device_id));
+  rex_env* h = new (std::nothrow) rex_env();
+  if (!h) return set_err(REX_ERR_ARG, "out of host memory");
+  h->kind = env_kind; h->variant = variant; h->device = device_id; h->B = batch; h->env_offset = env_offset; h->seed = seed;
+  h->dims = dims;
+  h->flags.endless = 0; h->flags.noisy = 0; h->flags.time_limit = 1; h->flags.max_steps = dims.max_episode_steps;
+  h->flags.noise_std = 0.0f;
+  h->dr.type = REX_DR_NONE; h->dr.dim = dims.task_dim;
+  const size_t B = (size_t)batch;
+  DevState& d = h->dev;
+  d.B = batch; d.env_offset = env_offset; d.seed = seed;
+  HIP_TRY(hipMalloc(&d.qpos, sizeof(float) * dims.nq * B));
+  HIP_TRY(hipMalloc(&d.qvel, sizeof(float) * dims.nv * B));
+  HIP_TRY(hipMalloc(&d.xi, sizeof(float) * dims.task_dim * B));
+  HIP_TRY(hipMalloc(&d.t, sizeof(int) * B));
+  HIP_TRY(hipMalloc(&d.episode, sizeof(unsigned) * B));
+  HIP_TRY(hipMalloc(&d.done, B));
+  HIP_TRY(hipMalloc(&d.counters, sizeof(unsigned long long) * 4));
+  HIP_TRY(hipMalloc(&h->d_scratch, sizeof(float) * MAX_XI));
+  HIP_TRY(hipMemset(d.qpos, 0, sizeof(float) * dims.nq * B));
+  HIP_TRY(hipMemset(d.qvel, 0, sizeof(float) * dims.nv * B));
+  HIP_TRY(hipMemset(d.t, 0, sizeof(int) * B));
+  HIP_TRY(hipMemset(d.episode, 0, sizeof(unsigned) * B));
+  HIP_TRY(hipMemset(d.done, 0, B));
+  HIP_TRY(hipMemset(d.counters, 0, sizeof(unsigned long long) * 4));
+  d.geom = nullptr;
+  float noise_var = 0;
+  switch (env_kind) {
+    case REX_CARTPOLE: { const float t0[4] = {9.8f, 1.0f, 0.1f, 0.5f}; memcpy(h->nominal_xi, t0, sizeof t0); break; }   // random_cartpole.py:74-78
+    case REX_HOPPER: host_derive<HopperSpec>(h, h->g_hopper); noise_var = HopperSpec::DEFAULT_NOISE_VAR; break;
+    case REX_HALFCHEETAH: host_derive<HalfCheetahSpec>(h, h->g_cheetah); h->nominal_xi[7] = 0.4f;                        // random_half_cheetah.py:37
+                          noise_var = HalfCheetahSpec::DEFAULT_NOISE_VAR; break;
+    case REX_WALKER2D: {
+      host_derive<Walker2dSpec>(h, h->g_walker);
+      for (int k = 0; k < 4; k++) h->nominal_xi[7 + k] = (float)Walker2dSpec::default_size[k];                           // random_walker2d.py:21
+      h->nominal_xi[11] = 0.9f; h->nominal_xi[12] = 1.9f;                                                                // random_walker2d.py:37
+      HIP_TRY(hipMalloc(&d.geom, sizeof(float) * geom_floats<Walker2dSpec>() * B));
+      noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
+  }
+  h->flags.noise_std = sqrtf(noise_var);
+  // xi <- nominal task, state <- qpos0
+  HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * dims.task_dim, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, dims.task_dim, (long long)B);
+  HIP_TRY(hipGetLastError());
+  if (env_kind == REX_WALKER2D) { int rc = launch_walker_derive(h, nullptr, 0, 0); if (rc) return rc; }
+  if (env_kind == REX_HOPPER || env_kind == REX_WALKER2D) {
+    float q0[MAX_XI] = {0}; q0[1] = 1.25f;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->d_scratch, q0, sizeof(float) * dims.nq, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.qpos, h->d_scratch, dims.nq, (long long)B);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  *out = h;
+  return REX_OK;
+}
+
+extern "C" int rex_destroy(rex_t* h) {
+  if (!h) return REX_OK;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  hipFree(h->dev.qpos); hipFree(h->dev.qvel); hipFree(h->dev.xi); hipFree(h->dev.t); hipFree(h->dev.episode);
+  hipFree(h->dev.done); hipFree(h->dev.counters); hipFree(h->d_scratch);
+  if (h->dev.geom) hipFree(h->dev.geom);
+  for (auto e : h->ev0) hipEventDestroy(e);
+  for (auto e : h->ev1) hipEventDestroy(e);
+  delete h;
+  return REX_OK;
+}
+
+extern "C" int rex_set_dr(rex_t* h, int dr_type, const float* params, int n_params, const float* lower_bounds) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  const int d = h->dims.task_dim;
+  DRParams& dr = h->dr;
+  switch (dr_type) {
+    case REX_DR_UNIFORM: case REX_DR_TRUNCNORM: case REX_DR_GAUSSIAN:
+      if (!params || n_params != 2 * d) return set_err(REX_ERR_ARG, "set_dr: expected %d params, got %d", 2 * d, n_params);
+      for (int i = 0; i < d; i++) { dr.a[i] = params[2 * i]; dr.b[i] = params[2 * i + 1]; }   // interleaved, random_env.py:102-121
+      break;
+    case REX_DR_FULLGAUSSIAN:
+      if (!params || n_params != d + d * d + 2 * d) return set_err(REX_ERR_ARG, "set_dr(fullgaussian): expected %d params, got %d", 3 * d + d * d, n_params);
+      for (int i = 0; i < d; i++) dr.a[i] = params[i];
+      for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) dr.chol[i * MAX_XI + j] = params[d + i * d + j];
+      for (int i = 0; i < d; i++) { dr.lo[i] = params[d + d * d + i]; dr.hi[i] = params[2 * d + d * d + i]; }
+      break;
+    case REX_DR_NONE: break;
+    default: return set_err(REX_ERR_ARG, "Unknown dr_type:%d", dr_type);   // random_env.py:90
+  }
+  for (int i = 0; i < d; i++) dr.lower[i] = lower_bounds ? lower_bounds[i] : 0.0f;
+  dr.type = dr_type; dr.dim = d;
+  return REX_OK;
+}
+extern "C" int rex_set_dr_training(rex_t* h, int flag) { if (!h) return set_err(REX_ERR_ARG, "null handle"); h->dr_training = flag ? 1 : 0; return REX_OK; }
+extern "C" int rex_set_flags(rex_t* h, int endless, int noisy, float noise_var) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  h->flags.endless = endless ? 1 : 0; h->flags.noisy = noisy ? 1 : 0;
+  if (noise_var >= 0) h->flags.noise_std = sqrtf(noise_var);
+  return REX_OK;
+}
+extern "C" int rex_set_autoreset(rex_t* h, int autoreset, int time_limit) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  h->autoreset = autoreset ? 1 : 0; h->flags.time_limit = time_limit ? 1 : 0;
+  return REX_OK;
+}
+extern "C" int rex_seed(rex_t* h, uint64_t seed) { if (!h) return set_err(REX_ERR_ARG, "null handle"); h->seed = seed; h->dev.seed = seed; return REX_OK; }
+
+static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, int reset_state, float* obs, hipStream_t st) {
+  const dim3 g(grid_for(h->B)), b(64);
+  if (resample && h->dr.type == REX_DR_NONE) return set_err(REX_ERR_STATE,
+      "sampling value of random env needs to be set before using sample_task() or set_random_task()");   // random_env.py:201
+  switch (h->kind) {
+    case REX_CARTPOLE: hipLaunchKernelGGL(cartpole_reset_kernel, g, b, 0, st, h->dev, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_HOPPER: hipLaunchKernelGGL(planar_reset_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_reset_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+  }
+  HIP_TRY(hipGetLastError());
+  if (h->kind == REX_WALKER2D && resample) return launch_walker_derive(h, mask, bit, st);
+  return REX_OK;
+}
+
+extern "C" int rex_reset(rex_t* h, const uint8_t* mask, float* obs_out, void* stream) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  // CartPole.reset() never resamples (random_cartpole.py:226-229); the MuJoCo envs do when dr_training
+  int resample = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
+  return do_reset(h, mask, 1, resample, 1, obs_out, (hipStream_t)stream);
+}
+extern "C" int rex_set_random_task(rex_t* h, const uint8_t* mask, void* stream) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return do_reset(h, mask, 1, 1, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
+                        uint8_t* truncated_out, float* terminal_obs_out, void* stream) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  if (!action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_step: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid_for(h->B)), b(64);
+  if (h->timing) {
+    if (h->ev_n >= h->ev0.size()) {
+      hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
+    }
+    HIP_TRY(hipEventRecord(h->ev0[h->ev_n], st));
+  }
+  switch (h->kind) {
+    case REX_CARTPOLE:
+      hipLaunchKernelGGL(cartpole_step_kernel, g, b, 0, st, h->dev, h->flags, (const int*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+    case REX_HOPPER:
+      hipLaunchKernelGGL(planar_step_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->g_hopper, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+    case REX_HALFCHEETAH:
+      hipLaunchKernelGGL(planar_step_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->g_cheetah, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+    case REX_WALKER2D:
+      hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+  }
+  if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
+  HIP_TRY(hipGetLastError());
+  h->step_count += h->B;
+  if (h->autoreset) {
+    int resample = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
+    return do_reset(h, h->dev.done, 2, resample, 1, obs_out, st);
+  }
+  return REX_OK;
+}
+
+static int copy_rows(float* dst, const float* src, int rows, long long B, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(float) * rows * (size_t)B, hipMemcpyDeviceToDevice, st));
+  return REX_OK;
+}
+extern "C" int rex_get_state(rex_t* h, float* qpos, float* qvel, void* stream) {
+  if (!h || !qpos || !qvel) return set_err(REX_ERR_ARG, "rex_get_state: null argument");
+  int rc = copy_rows(qpos, h->dev.qpos, h->dims.nq, h->B, (hipStream_t)stream); if (rc) return rc;
+  return copy_rows(qvel, h->dev.qvel, h->dims.nv, h->B, (hipStream_t)stream);
+}
+extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, void* stream) {
+  if (!h || !qpos || !qvel) return set_err(REX_ERR_ARG, "rex_set_state: null argument");
+  int rc = copy_rows(h->dev.qpos, qpos, h->dims.nq, h->B, (hipStream_t)stream); if (rc) return rc;
+  rc = copy_rows(h->dev.qvel, qvel, h->dims.nv, h->B, (hipStream_t)stream); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(h->dev.done, 0, (size_t)h->B, (hipStream_t)stream));   // steps_beyond_done = None
+  return REX_OK;
+}
+extern "C" int rex_get_task(rex_t* h, float* xi, void* stream) {
+  if (!h || !xi) return set_err(REX_ERR_ARG, "rex_get_task: null argument");
+  return copy_rows(xi, h->dev.xi, h->dims.task_dim, h->B, (hipStream_t)stream);
+}
+extern "C" int rex_set_task(rex_t* h, const float* xi, void* stream) {
+  if (!h || !xi) return set_err(REX_ERR_ARG, "rex_set_task: null argument");
+  int rc = copy_rows(h->dev.xi, xi, h->dims.task_dim, h->B, (hipStream_t)stream); if (rc) return rc;
+  if (h->kind == REX_WALKER2D) return launch_walker_derive(h, nullptr, 0, (hipStream_t)stream);
+  return REX_OK;
+}
+extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
+  if (!h || !obs_out) return set_err(REX_ERR_ARG, "rex_get_obs: null argument");
+  const dim3 g(grid_for(h->B)), b(64); hipStream_t st = (hipStream_t)stream;
+  switch (h->kind) {
+    case REX_CARTPOLE: hipLaunchKernelGGL(cartpole_obs_kernel, g, b, 0, st, h->dev, obs_out); break;
+    case REX_HOPPER: hipLaunchKernelGGL(planar_obs_kernel<HopperSpec>, g, b, 0, st, h->dev, obs_out); break;
+    case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_obs_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, obs_out); break;
+    case REX_WALKER2D: hipLaunchKernelGGL(planar_obs_kernel<Walker2dSpec>, g, b, 0, st, h->dev, obs_out); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return REX_OK;
+}
+
+extern "C" int64_t rex_step_count(const rex_t* h) { return h ? h->step_count : 0; }
+extern "C" int rex_get_counters(rex_t* h, int64_t* out) {
+  if (!h || !out) return set_err(REX_ERR_ARG, "rex_get_counters: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, h->dev.counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost));
+  return REX_OK;
+}
+extern "C" int rex_enable_timing(rex_t* h, int enable) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  h->timing = enable ? 1 : 0; h->ev_n = 0;
+  return REX_OK;
+}
+extern "C" int rex_read_timing(rex_t* h, float* ms_out, int max_n) {
+  if (!h || !ms_out) { set_err(REX_ERR_ARG, "rex_read_timing: null argument"); return REX_ERR_ARG; }
+  int n = 0;
+  for (size_t k = 0; k < h->ev_n && n < max_n; k++) {
+    if (hipEventSynchronize(h->ev1[k]) != hipSuccess) break;
+    float ms = 0; if (hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]) != hipSuccess) break;
+    ms_out[n++] = ms;
+  }
+  h->ev_n = 0;
+  return n;
+}

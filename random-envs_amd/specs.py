@@ -1,0 +1,77 @@
+"""Per-environment spec tables (pure data; usable without a GPU).
+
+Everything here is transcribed from the reference's task-definition files; the cited lines are
+paths inside gabrieletiboni/random-envs.
+"""
+from collections import namedtuple
+
+EnvSpec = namedtuple("EnvSpec", [
+    "kind",            # key of _native.ENV_KINDS
+    "names",           # dyn_ind_to_name
+    "search_bounds",   # get_search_bounds_mean(i)
+    "lower_bounds",    # get_task_lower_bound(i)
+    "nominal_task",    # get_task() of a freshly built env
+    "reward_threshold", "preferred_lr",
+    "noise_level",     # variance of the obs noise when noisy=True
+    "dr_on_reset",     # does reset() call set_random_task() when dr_training?
+])
+
+_M = (0.5, 10.0)
+
+CARTPOLE = EnvSpec(                                   # random_envs/random_cartpole.py
+    kind="cartpole",
+    names=["gravity", "cart_mass", "pole_mass", "pole_length"],                 # :104-107
+    search_bounds=[(2., 20.0), (0.5, 3.0), (0.05, 0.3), (0.1, 1.)],            # :127-132
+    lower_bounds=[0.1, 0.1, 0.1, 0.1],                                          # :140-145
+    nominal_task=[9.8, 1.0, 0.1, 0.5],                                          # :74-78
+    reward_threshold=500, preferred_lr=None, noise_level=0.0,                  # :120
+    dr_on_reset=False)                                                          # :226-229
+
+HOPPER = EnvSpec(                                     # random_envs/jinja/random_hopper.py
+    kind="hopper",
+    names=["torsomass", "thighmass", "legmass", "footmass"],                    # :42
+    search_bounds=[_M] * 4,                                                     # :52-57
+    lower_bounds=[0.1] * 4,                                                     # :65-70
+    # body_mass[1:] of the compiled hopper.xml under MuJoCo 2.1.0 (1000*pi*r^2*(L+r))
+    nominal_task=[3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 5.0893800988154645],
+    reward_threshold=1750, preferred_lr=0.0005, noise_level=1e-4,              # :44-45,28
+    dr_on_reset=True)                                                           # :117-118
+
+HALFCHEETAH = EnvSpec(                                # random_envs/jinja/random_half_cheetah.py
+    kind="halfcheetah",
+    names=["torso", "bthigh", "bshin", "bfoot", "fthigh", "fshin", "ffoot", "friction"],   # :46
+    search_bounds=[_M] * 7 + [(0.1, 2.0)],                                      # :55-64
+    lower_bounds=[0.1] * 7 + [0.02],                                            # :72-81
+    nominal_task=[6.360313323782975, 1.5352480417754572, 1.5809399477806787, 1.0691906005221934,
+                  1.4255874673629243, 1.1788511749347258, 0.8498694516971279, 0.4],   # settotalmass=14; friction :37
+    reward_threshold=4500, preferred_lr=0.0005, noise_level=1e-4,              # :48-49,30
+    dr_on_reset=True)                                                           # :128-129
+
+WALKER2D = EnvSpec(                                   # random_envs/jinja/random_walker2d.py
+    kind="walker2d",
+    names=["torso", "thigh", "leg", "foot", "thigh_left", "leg_left", "foot_left",
+           "torsosize", "thighsize", "legsize", "footsize", "friction_right", "friction_left"],   # :46
+    search_bounds=[_M] * 7 + [(0.15, 1.0)] * 4 + [(0.1, 3.0)] * 2,              # :56-73
+    lower_bounds=[0.1] * 7 + [0.1] * 4 + [0.05] * 2,                            # :80-96
+    nominal_task=[3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 2.9405307237600464,
+                  3.9269908169872414, 2.7143360527015816, 2.9405307237600464,
+                  0.4, 0.45, 0.6, 0.2, 0.9, 1.9],                               # :21,37
+    reward_threshold=2200, preferred_lr=0.0005, noise_level=1e-3,              # :48-49,30
+    dr_on_reset=True)                                                           # :145-146
+
+SPECS = {"cartpole": CARTPOLE, "hopper": HOPPER, "halfcheetah": HALFCHEETAH, "walker2d": WALKER2D}
+
+# gym ids registered by the reference: id -> (kind, kwargs)
+IDS = {
+    "RandomCartPole-v0": ("cartpole", {}),                       # random_cartpole.py:291-296
+    "RandomHopper-v0": ("hopper", {}),                           # random_hopper.py:155-159
+    "RandomHopperNoisy-v0": ("hopper", {"noisy": True}),         # random_hopper.py:161-166
+    "RandomHalfCheetah-v0": ("halfcheetah", {}),                 # random_half_cheetah.py:161-165
+    "RandomHalfCheetahNoisy-v0": ("halfcheetah", {"noisy": True}),   # :167-172
+    "RandomWalker2d-v0": ("walker2d", {}),                       # random_walker2d.py:188-192
+    "RandomWalker2dNoisy-v0": ("walker2d", {"noisy": True}),     # :194-199
+}
+# ids of the reference not built yet: creating them raises
+PENDING_IDS = ["RandomHumanoid-v0", "RandomHumanoidNoisy-v0", "RandomHopperUnmodeled-v0",
+               "RandomHalfCheetahUnmodeled-v0", "RandomWalker2dUnmodeled-v0", "RandomHumanoidUnmodeled-v0"]
+MAX_EPISODE_STEPS = 500

@@ -1,0 +1,229 @@
+"""VecRandomEnv: the reference's RandomEnv / MujocoEnv surface for a batch of environments.
+
+Mirrors, method for method, ``random_envs/random_env.py`` (DR state: set_dr_distribution,
+get_dr_distribution, set_dr_training, sample_task(s), set_random_task, search bounds,
+denormalize_parameters, load_dr_distribution_from_file) and the gym protocol of the task files
+(reset, step -> (obs, reward, done, info), get_task, set_task, seed).  All tensors are
+torch ROCm tensors; obs is ``[batch, obs_dim]`` (a zero-copy transposed view of the kernels'
+SoA ``[obs_dim][batch]`` buffer), reward ``[batch]`` f32, done ``[batch]`` bool.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native
+from .dr import DRConfig
+from .specs import MAX_EPISODE_STEPS, SPECS
+
+
+class _Box:
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.full(shape, low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype)
+        self.shape, self.dtype = tuple(shape), dtype
+
+
+class _Discrete:
+    def __init__(self, n):
+        self.n = n
+        self.shape, self.dtype = (), np.int64
+
+
+class VecRandomEnv(DRConfig):
+    def __init__(self, kind, batch=1, device=0, seed=0, env_offset=0, noisy=False, env_id=None,
+                 autoreset=True, time_limit=True):
+        import torch
+        self._torch = torch
+        self.spec = SPECS[kind]
+        self.kind, self.env_id = kind, env_id
+        self.batch, self.num_envs = int(batch), int(batch)
+        self.device = torch.device("cuda", device)
+        L = _native.lib()   # raises loudly when the HIP library is missing
+        dims = _native.RexDims()
+        _native.check(L.rex_get_dims(_native.ENV_KINDS[kind], ctypes.byref(dims)))
+        self.dims = dims
+        self.task_dim = dims.task_dim
+        self._h = ctypes.c_void_p()
+        _native.check(L.rex_create(_native.ENV_KINDS[kind], 0, self.batch, device, seed, env_offset, ctypes.byref(self._h)))
+        self._L = L
+        DRConfig.__init__(self, self.spec)   # RandomEnv.__init__ state + per-env tables
+        self.noisy = bool(noisy)
+        self.max_episode_steps = MAX_EPISODE_STEPS
+        self.autoreset, self.time_limit = bool(autoreset), bool(time_limit)
+        if dims.discrete_action:
+            self.action_space = _Discrete(2)                                  # random_cartpole.py:96
+        else:
+            self.action_space = _Box(dims.act_low, dims.act_high, (dims.act_dim,))   # jinja_mujoco_env.py:99-103
+        self.observation_space = _Box(-np.inf, np.inf, (dims.obs_dim,))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        B = self.batch
+        self._obs = torch.zeros(dims.obs_dim, B, **f32)
+        self._term_obs = torch.zeros(dims.obs_dim, B, **f32)
+        self._reward = torch.zeros(B, **f32)
+        self._done = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self._trunc = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self._act = torch.zeros(dims.act_dim, B, dtype=torch.int32 if dims.discrete_action else torch.float32,
+                                device=self.device)
+        self._push_flags()
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _push_flags(self):
+        _native.check(self._L.rex_set_flags(self._h, int(self.endless), int(self.noisy), float(self.noise_level)))
+        _native.check(self._L.rex_set_autoreset(self._h, int(self.autoreset), int(self.time_limit)))
+        _native.check(self._L.rex_set_dr_training(self._h, int(self.dr_training)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.rex_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ RandomEnv surface (device side)
+    def _push_dr(self):
+        d = self.task_dim
+        lower = np.array(self.spec.lower_bounds, dtype=np.float32)
+        if self.sampling == 'uniform':
+            p = np.stack([self.min_task, self.max_task], 1).ravel()
+        elif self.sampling in ('truncnorm', 'gaussian'):
+            p = np.stack([self.mean_task, self.stdev_task], 1).ravel()
+        else:
+            lo, hi = self.get_task_search_bounds()
+            chol = np.linalg.cholesky(np.asarray(self.cov_task, dtype=np.float64))
+            p = np.concatenate([self.mean_task, chol.ravel(), lo, hi])
+        p = np.ascontiguousarray(p, dtype=np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        _native.check(self._L.rex_set_dr(self._h, _native.DR_TYPES[self.sampling], p.ctypes.data_as(fp), p.size,
+                                         lower.ctypes.data_as(fp)))
+
+    def _set_dr_training_native(self):
+        _native.check(self._L.rex_set_dr_training(self._h, int(self.dr_training)))
+
+    def set_random_task(self, mask=None):     # random_env.py:37-39, for every (masked) env of the batch
+        if self.sampling is None:
+            raise ValueError('sampling value of random env needs to be set before using sample_task() or '
+                             'set_random_task(). Set it by uploading a DR distr.')
+        m = self._mask_ptr(mask)
+        _native.check(self._L.rex_set_random_task(self._h, m, self._stream()))
+
+    def sample_task(self):
+        """One xi per env, WITHOUT applying it: [batch, task_dim] (the reference returns one vector)."""
+        return self.sample_tasks(1)[0]
+
+    def sample_tasks(self, num_tasks=1):      # random_env.py:145-146
+        keep = self.get_task().clone()
+        out = []
+        for _ in range(num_tasks):
+            self.set_random_task()
+            out.append(self.get_task().clone())
+        self.set_task(keep)
+        return self._torch.stack(out)
+
+    # ------------------------------------------------------------------ task / state
+    def get_task(self):
+        xi = self._torch.empty(self.task_dim, self.batch, dtype=self._torch.float32, device=self.device)
+        _native.check(self._L.rex_get_task(self._h, ctypes.c_void_p(xi.data_ptr()), self._stream()))
+        return xi.t()
+
+    def set_task(self, *task):
+        """set_task(xi[batch, task_dim]) or set_task(*xi_scalars) broadcast to every env."""
+        t = self._torch
+        if len(task) == 1 and hasattr(task[0], "__len__"):
+            x = t.as_tensor(np.asarray(task[0].cpu() if hasattr(task[0], "cpu") else task[0]), dtype=t.float32)
+        else:
+            x = t.as_tensor(np.asarray(task, dtype=np.float32))
+        if x.dim() == 1:
+            x = x.unsqueeze(0).expand(self.batch, -1)
+        assert tuple(x.shape) == (self.batch, self.task_dim), "task must be [batch, task_dim]"
+        xi = x.t().contiguous().to(self.device)
+        _native.check(self._L.rex_set_task(self._h, ctypes.c_void_p(xi.data_ptr()), self._stream()))
+        t.cuda.current_stream(self.device).synchronize()
+
+    def get_state(self):
+        t = self._torch
+        q = t.empty(self.dims.nq, self.batch, dtype=t.float32, device=self.device)
+        v = t.empty(self.dims.nv, self.batch, dtype=t.float32, device=self.device)
+        _native.check(self._L.rex_get_state(self._h, ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(v.data_ptr()), self._stream()))
+        return q.t(), v.t()
+
+    def set_state(self, qpos, qvel):          # jinja_mujoco_env.py:146-154
+        t = self._torch
+        q = t.as_tensor(qpos, dtype=t.float32).reshape(-1, self.dims.nq)
+        v = t.as_tensor(qvel, dtype=t.float32).reshape(-1, self.dims.nv)
+        assert q.shape[0] in (1, self.batch)
+        q = q.expand(self.batch, -1).t().contiguous().to(self.device)
+        v = v.expand(self.batch, -1).t().contiguous().to(self.device)
+        _native.check(self._L.rex_set_state(self._h, ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(v.data_ptr()), self._stream()))
+        t.cuda.current_stream(self.device).synchronize()
+
+    def state_vector(self):                   # jinja_mujoco_env.py:231-235
+        q, v = self.get_state()
+        return self._torch.cat([q, v], 1)
+
+    def seed(self, seed=None):                # jinja_mujoco_env.py:109-111
+        seed = 0 if seed is None else int(seed)
+        _native.check(self._L.rex_seed(self._h, seed))
+        return [seed]
+
+    # ------------------------------------------------------------------ gym protocol
+    def _mask_ptr(self, mask):
+        if mask is None:
+            return None
+        t = self._torch
+        self._mask = t.as_tensor(mask).to(device=self.device, dtype=t.uint8).contiguous()
+        assert self._mask.numel() == self.batch
+        return ctypes.c_void_p(self._mask.data_ptr())
+
+    def reset(self, mask=None):
+        m = self._mask_ptr(mask)
+        _native.check(self._L.rex_reset(self._h, m, ctypes.c_void_p(self._obs.data_ptr()), self._stream()))
+        if mask is not None:   # lanes not reset still need a valid observation
+            pass
+        return self._obs.t()
+
+    def step(self, action):
+        t = self._torch
+        a = t.as_tensor(action, device=self.device)
+        if self.dims.discrete_action:
+            a = a.reshape(self.batch).to(t.int32)
+            self._act.view(-1).copy_(a)
+        else:
+            a = a.reshape(self.batch, self.dims.act_dim).to(t.float32)
+            self._act.copy_(a.t())
+        _native.check(self._L.rex_step(
+            self._h, ctypes.c_void_p(self._act.data_ptr()), ctypes.c_void_p(self._obs.data_ptr()),
+            ctypes.c_void_p(self._reward.data_ptr()), ctypes.c_void_p(self._done.data_ptr()),
+            ctypes.c_void_p(self._trunc.data_ptr()), ctypes.c_void_p(self._term_obs.data_ptr()), self._stream()))
+        info = {"TimeLimit.truncated": self._trunc.bool(), "terminal_observation": self._term_obs.t()}
+        return self._obs.t(), self._reward, self._done.bool(), info
+
+    def step_soa(self, action_soa):
+        """Zero-copy hot path: ``action_soa`` is a contiguous [act_dim, batch] tensor on the env's
+        device; returns the SoA obs/reward/done buffers (no transposes, no info dict)."""
+        _native.check(self._L.rex_step(
+            self._h, ctypes.c_void_p(action_soa.data_ptr()), ctypes.c_void_p(self._obs.data_ptr()),
+            ctypes.c_void_p(self._reward.data_ptr()), ctypes.c_void_p(self._done.data_ptr()), None, None, self._stream()))
+        return self._obs, self._reward, self._done
+
+    def step_count(self):
+        return int(self._L.rex_step_count(self._h))
+
+    def counters(self):
+        out = (ctypes.c_int64 * 4)()
+        _native.check(self._L.rex_get_counters(self._h, out))
+        return dict(nonfinite=out[0], gaussian_fail=out[1], solver_capped=out[2])
+
+    def enable_timing(self, flag=True):
+        _native.check(self._L.rex_enable_timing(self._h, int(flag)))
+
+    def read_timing(self, max_n=65536):
+        buf = (ctypes.c_float * max_n)()
+        n = self._L.rex_read_timing(self._h, buf, max_n)
+        return np.frombuffer(buf, dtype=np.float32, count=max(n, 0)).copy()

@@ -1,0 +1,135 @@
+"""Parity of the planar HIP kernels (hopper / walker2d / half-cheetah), called through the C-ABI,
+against the fp64 oracle on identical (qpos, qvel, action, xi); plus size-independent properties at
+BASELINE.json's full batch sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IDS = {"hopper": "RandomHopper-v0", "walker2d": "RandomWalker2d-v0", "halfcheetah": "RandomHalfCheetah-v0"}
+# fp32 tolerances (stated per quantity): established with the host fp32 instantiation of the same
+# code in tests/test_planar_engine_host.py
+TOL_QPOS_P99, TOL_QVEL_REL_P99, TOL_QVEL_REL_MED = 2e-5, 2e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _step_from(env, torch, q, v, xi, a):
+    env.set_task(np.asarray(xi, dtype=np.float32))
+    env.set_state(q, v)
+    obs, r, d, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+    qq, vv = env.get_state()
+    return obs.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), qq.cpu().numpy(), vv.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind", ["hopper", "walker2d", "halfcheetah"])
+def test_step_parity_on_rollout_states(torch_mod, kind):
+    import random_envs_amd as rex
+    from oracle_bindings import DIMS, oracle_batch_step, rollout_states
+    n = 2048; d = DIMS[kind]
+    q, v, xi = rollout_states(kind, n, steps_max=60, seed=11)
+    # the kernel sees fp32 inputs: give the oracle the same rounded values
+    q = q.astype(np.float32).astype(np.float64); v = v.astype(np.float32).astype(np.float64)
+    xi = xi.astype(np.float32).astype(np.float64)
+    a = np.random.RandomState(5).uniform(-1.2, 1.2, (n, d["nu"])).astype(np.float32).astype(np.float64)
+    env = rex.make(IDS[kind], batch=n, autoreset=False)
+    obs, r, dn, qq, vv = _step_from(env, torch_mod, q, v, xi, a)
+    ref = oracle_batch_step(kind, q, v, a, xi)
+    eq = np.abs(qq - ref["qpos"]).max(1)
+    ev = np.abs(vv - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    assert np.isfinite(qq).all() and np.isfinite(vv).all()
+    assert np.percentile(eq, 99) < TOL_QPOS_P99, (np.percentile(eq, 99), eq.max())
+    assert np.percentile(ev, 99) < TOL_QVEL_REL_P99, (np.percentile(ev, 99), ev.max())
+    assert np.median(ev) < TOL_QVEL_REL_MED
+    # obs = concat(qpos[1:], qvel); reward; done
+    assert np.array_equal(obs, np.concatenate([qq[:, 1:], vv], 1))
+    er = np.abs(r - ref["reward"])
+    assert np.percentile(er, 99) < 5e-3 and np.median(er) < 2e-4, (np.percentile(er, 99), er.max())
+    # done differs only where a threshold is within fp32 rounding
+    mism = dn != ref["done"]
+    assert mism.mean() < 0.005
+    assert env.counters()["solver_capped"] == 0
+    env.close()
+
+
+def test_hopper_contact_rich_and_limit_states(torch_mod):
+    """random (not rollout) states: deeper penetrations, joint limits violated, large velocities"""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_batch_step
+    from random_envs_amd.specs import SPECS
+    n = 4096; rng = np.random.RandomState(7)
+    xi = np.array(SPECS["hopper"].nominal_task) * rng.uniform(0.5, 1.5, (n, 4))
+    q = rng.uniform(-0.4, 0.4, (n, 6)); q[:, 1] = rng.uniform(1.05, 1.4, n); q[:, 5] = rng.uniform(-0.9, 0.9, n)
+    v = rng.uniform(-3, 3, (n, 6)); a = rng.uniform(-1.2, 1.2, (n, 3))
+    q, v, xi, a = [x.astype(np.float32).astype(np.float64) for x in (q, v, xi, a)]
+    env = rex.make("RandomHopper-v0", batch=n, autoreset=False)
+    obs, r, dn, qq, vv = _step_from(env, torch_mod, q, v, xi, a)
+    ref = oracle_batch_step("hopper", q, v, a, xi)
+    ev = np.abs(vv - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    assert np.percentile(ev, 99) < 5e-4 and np.median(ev) < 1e-5, (np.percentile(ev, 99), ev.max())
+    env.close()
+
+
+def test_full_batch_properties_hopper(torch_mod):
+    """B = 32768 (the north-star batch): determinism, x-translation invariance, shard independence."""
+    import random_envs_amd as rex
+    torch = torch_mod
+    B = 32768
+    def run(env_offset=0, batch=B, shift=0.0, steps=3):
+        env = rex.make("RandomHopper-v0", batch=batch, seed=42, env_offset=env_offset, autoreset=False)
+        env.set_dr_distribution("uniform", [3.0, 4.0, 3.5, 4.5, 2.2, 3.2, 4.5, 5.5])
+        env.set_dr_training(True)
+        env.reset()
+        if shift:
+            q, v = env.get_state(); q = q.clone(); q[:, 0] += shift; env.set_state(q, v)
+        g = torch.Generator().manual_seed(1)
+        acts = (torch.rand(steps, B, 3, generator=g) * 2 - 1)[:, env_offset:env_offset + batch]
+        outs = []
+        for t in range(steps):
+            obs, r, d, _ = env.step(acts[t])
+            outs.append((obs.clone(), r.clone(), d.clone()))
+        xi = env.get_task().clone(); env.close()
+        return outs, xi
+    full, xi = run()
+    again, _ = run()
+    for (o1, r1, d1), (o2, r2, d2) in zip(full, again):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)      # bitwise deterministic
+    lo = torch.tensor([3.0, 3.5, 2.2, 4.5], device=xi.device); hi = torch.tensor([4.0, 4.5, 3.2, 5.5], device=xi.device)
+    assert (xi >= lo).all() and (xi <= hi).all()
+    assert torch.allclose(xi.mean(0), (lo + hi) / 2, atol=0.01)
+    shifted, _ = run(shift=100.0)
+    for (o1, r1, d1), (o2, r2, d2) in zip(full, shifted):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2)         # obs excludes x; reward uses the in-kernel dx
+    half, xih = run(env_offset=B // 2, batch=B // 2)
+    for (o1, r1, d1), (o2, r2, d2) in zip(full, half):
+        assert torch.equal(o1[B // 2:], o2) and torch.equal(r1[B // 2:], r2)            # sharding does not change results
+    assert torch.equal(xi[B // 2:], xih)
+
+
+@pytest.mark.parametrize("kind,B", [("halfcheetah", 16384), ("walker2d", 8192)])
+def test_full_batch_finite_and_deterministic(torch_mod, kind, B):
+    import random_envs_amd as rex
+    from random_envs_amd.specs import SPECS
+    torch = torch_mod
+    nom = np.array(SPECS[kind].nominal_task)
+    def run():
+        env = rex.make(IDS[kind] if kind != "halfcheetah" else "RandomHalfCheetahNoisy-v0", batch=B, seed=9)
+        env.set_dr_distribution("uniform", np.stack([0.8 * nom, 1.2 * nom], 1).ravel().tolist())
+        env.set_dr_training(True)
+        env.reset()
+        g = torch.Generator().manual_seed(2)
+        tot = 0
+        for t in range(20):
+            obs, r, d, _ = env.step(torch.rand(B, env.dims.act_dim, generator=g) * 2 - 1)
+            assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+            tot += r.sum().item()
+        c = env.counters(); env.close()
+        return obs.clone(), tot, c
+    o1, t1, c1 = run(); o2, t2, c2 = run()
+    assert torch.equal(o1, o2) and t1 == t2
+    assert c1["nonfinite"] == 0

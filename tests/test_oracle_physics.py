@@ -1,0 +1,67 @@
+"""Self-consistency of the fp64 physics oracle (oracle/mjo_core.c).  True mujoco-py parity is
+UNPINNED (MuJoCo absent, reference has no numeric tests) -- these tests pin what can be pinned:
+recalled public model constants, conservation laws and force balance."""
+import numpy as np
+import pytest
+
+from oracle_bindings import (oracle_batch_step, oracle_constants, oracle_energy_drift, oracle_forward)
+from random_envs_amd.specs import SPECS
+
+
+def test_compiled_masses_match_public_mujoco_py_constants():
+    """body_mass of the mujoco-py-era gym models (recalled public constants)."""
+    hop = oracle_constants("hopper")
+    assert np.allclose(hop["body_mass"][1:], [3.53429174, 3.92699082, 2.71433605, 5.0893801], atol=5e-9)
+    che = oracle_constants("halfcheetah")
+    assert np.allclose(che["body_mass"][1:], [6.36031332, 1.53524804, 1.58093995, 1.0691906, 1.42558747,
+                                              1.17885117, 0.84986945], atol=5e-9)
+    assert abs(che["body_mass"].sum() - 14.0) < 1e-12          # settotalmass, half_cheetah.xml:54
+    wal = oracle_constants("walker2d")
+    assert np.allclose(wal["body_mass"][1:], [3.53429174, 3.92699082, 2.71433605, 2.94053072] + [3.92699082, 2.71433605, 2.94053072], atol=5e-9)
+    for k in ("hopper", "halfcheetah", "walker2d"):
+        assert np.allclose(oracle_constants(k)["body_mass"][1:], SPECS[k].nominal_task[:len(oracle_constants(k)["body_mass"]) - 1], rtol=1e-12)
+
+
+def test_model_dimensions():
+    assert [oracle_constants("hopper")[k] for k in ("nbody", "nq", "nv", "ngeom", "nu", "npair")] == [5, 6, 6, 5, 3, 7]
+    assert [oracle_constants("walker2d")[k] for k in ("nbody", "nq", "nv", "ngeom", "nu", "npair")] == [8, 9, 9, 8, 6, 7]
+    assert [oracle_constants("halfcheetah")[k] for k in ("nbody", "nq", "nv", "ngeom", "nu", "npair")] == [8, 9, 9, 9, 6, 8]
+    assert list(oracle_constants("hopper")["qpos0"]) == [0, 1.25, 0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("kind,nq,tol", [("hopper", 6, 1e-11), ("walker2d", 9, 1e-9), ("halfcheetah", 9, 1e-3)])
+def test_energy_conservation(kind, nq, tol):
+    """M(q) and c(q,v) are consistent: a conservative copy of the model keeps KE+PE under RK4."""
+    rng = np.random.RandomState(0)
+    for _ in range(3):
+        q = rng.uniform(-.5, .5, nq); q[1] += 3; v = rng.uniform(-2, 2, nq)
+        e0, e1 = oracle_energy_drift(kind, 100, q, v)
+        assert abs(e1 - e0) <= tol * abs(e0)
+    if kind == "halfcheetah":   # the residual there is RK4 truncation on the stiff joint springs
+        e0, e1 = oracle_energy_drift(kind, 100, q, v, keep_springs=False)
+        assert abs(e1 - e0) <= 1e-8 * abs(e0)
+
+
+def test_free_fall_and_weight_balance():
+    xi = np.array(SPECS["hopper"].nominal_task)
+    out = oracle_forward("hopper", [0, 1.25, 0, 0, 0, 0], np.zeros(6), np.zeros(3), xi)
+    assert out["ncon"] == 0 and np.allclose(out["qacc"], [0, -9.81, 0, 0, 0, 0], atol=1e-12)
+    # half-cheetah dropped from qpos0 settles on both feet: contact forces carry the weight
+    xi = np.array(SPECS["halfcheetah"].nominal_task)
+    q = np.zeros((1, 9)); v = np.zeros((1, 9))
+    for _ in range(80):
+        o = oracle_batch_step("halfcheetah", q, v, np.zeros((1, 6)), xi[None], nthreads=1, tolerance=0.0)
+        q, v = o["qpos"], o["qvel"]
+    f = oracle_forward("halfcheetah", q[0], v[0], np.zeros(6), xi)
+    assert abs(f["force"].sum() - 14 * 9.81) < 0.05 and np.abs(v).max() < 1e-3
+
+
+def test_xi_changes_mass_not_inertia():
+    """set_task writes body_mass only.  Doubling every mass with gravity-free,
+    contact-free state must NOT simply halve accelerations (inertia stays nominal)."""
+    xi = np.array(SPECS["hopper"].nominal_task)
+    q = [0, 3.0, 0.1, -0.3, -0.2, 0.1]; v = np.zeros(6); a = np.array([1.0, -0.5, 0.3])
+    a1 = oracle_forward("hopper", q, v, a, xi)["qacc"]; a2 = oracle_forward("hopper", q, v, a, 2 * xi)["qacc"]
+    M1 = oracle_forward("hopper", q, v, a, xi)["M"]; M2 = oracle_forward("hopper", q, v, a, 2 * xi)["M"]
+    assert not np.allclose(M2, 2 * M1) and np.allclose(M2[0, 0], 2 * M1[0, 0])
+    assert not np.allclose(a2[3:], a1[3:] / 2, rtol=1e-3)
