@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 NOMINAL = [3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 5.0893800988154645]
 
 
-def cpu_baseline(batch, steps, seed=0):
+def cpu_baseline(batch, steps, seed=0, min_seconds=12.0):
     """oracle ("port") timed on the host cores: `batch` envs x `steps` env-steps from reset states."""
     import numpy as np
     from oracle_bindings import oracle_rollout
@@ -43,12 +43,17 @@ def cpu_baseline(batch, steps, seed=0):
     xi = np.array(NOMINAL) * rng.uniform(0.9, 1.1, (batch, 4))
     acts = rng.uniform(-1, 1, (steps, batch, 3))
     oracle_rollout("hopper", q[:64], v[:64], acts[:2, :64], xi[:64], nthreads=cores)   # warm the library
+    # bounded sample: repeat the (batch x steps) rollout from the reset states until >= min_seconds
+    # of wall time has been spent (MuJoCo's own solver tolerance 1e-8)
+    reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    oracle_rollout("hopper", q, v, acts, xi, nthreads=cores)          # MuJoCo's own solver tolerance (1e-8)
-    dt = time.perf_counter() - t0
+    while dt < min_seconds and reps < 64:
+        oracle_rollout("hopper", q, v, acts, xi, nthreads=cores)
+        reps += 1; dt = time.perf_counter() - t0
+    steps = steps * reps
     return dict(value=batch * steps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d steps from reset states, U(-1,1) actions, xi nominal+-10%%, fp64, %d threads, %.1f s"
-                       % (batch, steps, cores, dt))
+                sample="%d envs x %d env-steps (%d-step rollouts from reset states, %d repeats), U(-1,1) actions, "
+                       "xi nominal+-10%%, fp64, %d threads, %.1f s" % (batch, steps, steps // reps, reps, cores, dt))
 
 
 def main():

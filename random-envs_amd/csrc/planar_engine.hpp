@@ -409,7 +409,7 @@ struct SolveStats { int iters; bool capped; };
 // ([3P] engine_solver, Newton, pyramidal cones): exact Hessian M + J^T D_active J with the tree
 // sparsity of M, L^T D L factorisation, exact line search on the piecewise-quadratic 1-D cost.
 // All lanes of a wave iterate together; a lane that has converged keeps alpha = 0.
-template <class T, class S, int MAXIT = 8>
+template <class T, class S, int MAXIT = 24>
 REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
                                const Kin<T, S>& K, const Constraints<T, S>& C, const SolParams<T>& sp, T (&qacc)[S::NV]) {
   static_for<0, S::NV>([&](auto II) { qacc[II] = qacc_smooth[II]; });
