@@ -15,6 +15,7 @@
 // to compare this exact code in fp32/fp64 against the independent 3-D oracle without a GPU.
 #pragma once
 #include <math.h>
+#include <stdio.h>
 
 #include "planar_spec.hpp"
 
@@ -187,26 +188,49 @@ REX_HD T impedance(T dmin, T dmax, T width, T x_abs) {
   return (dmin == dmax) ? dmin : imp;
 }
 
-// One floor-contact slot (one capsule end).  J rows are never stored: they are rebuilt from the
-// contact point and the joint anchors whenever needed.
-template <class T>
-struct ContactSlot {
-  T px, pz;      // contact point relative to the root anchor
-  T D;           // 1/R of the pyramid edges
-  T an, at;      // reference accelerations: edges are (an +/- at) and an (twice)
-  T mu;
-  bool active;
+// Optimisation barrier: tells the compiler the value may have changed.  Used at the top of the
+// solver loops so that LLVM's loop-invariant code motion does not hoist every lever arm and
+// Jacobian entry of every contact slot out of the loops (it does, speculatively, and the ~200
+// hoisted values then spill to scratch memory: 590 MB of HBM writes per launch were measured).
+template <class T> REX_HD void opaque(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#else
+  (void)x;
+#endif
+}
+
+// fast reciprocal / division: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE sequence.
+// The parity tolerance (1e-4 relative on qvel) is four orders above its error.
+REX_HD float rcp_t(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(a);
+#else
+  return 1.0f / a;
+#endif
+}
+REX_HD double rcp_t(double a) { return 1.0 / a; }
+
+// Constraint data of one configuration.  J rows are never stored: they are rebuilt from the
+// contact point and the joint anchors whenever needed.  Slot k = 2*geom + end.
+template <class T, class S>
+struct Constraints {
+  static constexpr int NC = 2 * S::NG;
+  T px[NC], pz[NC];      // contact point relative to the root anchor
+  T D[NC];               // 1/R of the pyramid edges
+  T an[NC], at[NC];      // reference accelerations: edges are (an +/- at) and an (twice)
+  unsigned con_mask;     // bit k: slot k within margin
+  T lsig[S::NB], lD[S::NB], laref[S::NB];   // joint limits: row = lsig * e_dof
+  unsigned lim_mask;
+  bool any;              // any row at all in this lane
+  bool self_possible;    // a capsule-capsule self contact may exist (bounding-circle cull)
 };
-// One capsule-capsule self-contact (condim 1)
-template <class T>
-struct SelfSlot {
-  T px, pz, nx, nz, D, aref;
-  bool active;
-};
-template <class T>
-struct LimitSlot {
-  T sigma, D, aref;   // row = sigma * e_dof
-  bool active;
+// capsule-capsule self contacts (condim 1); only materialised on the rare path
+template <class T, class S>
+struct SelfRows {
+  static constexpr int NS = S::NSELF > 0 ? 2 * S::NSELF : 1;   // up to two contacts per pair (parallel axes)
+  T px[NS], pz[NS], nx[NS], nz[NS], D[NS], aref[NS];
+  unsigned mask;
 };
 
 // (t, n) components of J_point * x for a point P on body B
@@ -219,6 +243,19 @@ REX_HD void jdot(const Kin<T, S>& K, T px, T pz, const T (&x)[S::NV], T& t, T& n
       constexpr T sj = T(S::sgn[j]);
       T rx = px - K.A[j][0], rz = pz - K.A[j][1];
       t += sj * rz * x[j + 2]; n -= sj * rx * x[j + 2];
+    }
+  });
+}
+// the same for two vectors at once (shares the lever arms)
+template <class T, class S, int B>
+REX_HD void jdot2(const Kin<T, S>& K, T px, T pz, const T (&x)[S::NV], const T (&y)[S::NV], T& tx, T& nx, T& ty, T& ny) {
+  tx = x[0]; nx = x[1]; ty = y[0]; ny = y[1];
+  static_for<0, S::NB>([&](auto JJ) {
+    constexpr int j = JJ;
+    if constexpr (is_anc_or_self<S>(j, B)) {
+      constexpr T sj = T(S::sgn[j]);
+      T rx = sj * (px - K.A[j][0]), rz = sj * (pz - K.A[j][1]);
+      tx += rz * x[j + 2]; nx -= rx * x[j + 2]; ty += rz * y[j + 2]; ny -= rx * y[j + 2];
     }
   });
 }
@@ -261,13 +298,17 @@ REX_HD void hess_accum(const Kin<T, S>& K, T px, T pz, T ctt, T cnt, T cnn, T (&
   });
 }
 
-template <class T, class S>
-struct Constraints {
-  ContactSlot<T> con[2 * S::NG];
-  LimitSlot<T> lim[S::NB];
-  SelfSlot<T> self[S::NSELF > 0 ? 2 * S::NSELF : 1];   // up to two contacts per pair (parallel axes)
-  bool any;
-};
+// capsule centre / half-axis of geom g in world axes (relative to the root anchor)
+template <class T, class S, int g>
+REX_HD void capsule_pose(const Kin<T, S>& K, const PlanarGeom<T, S>& G, T (&p)[2], T (&a)[2], T& l) {
+  constexpr int b = S::geom_body[g];
+  T e1x, e1z, e2x, e2z;
+  rot(K.c[b], K.s[b], G.e1[g][0], G.e1[g][1], e1x, e1z); rot(K.c[b], K.s[b], G.e2[g][0], G.e2[g][1], e2x, e2z);
+  p[0] = K.A[b][0] + T(0.5) * (e1x + e2x); p[1] = K.A[b][1] + T(0.5) * (e1z + e2z);
+  T hx = T(0.5) * (e1x - e2x), hz = T(0.5) * (e1z - e2z);
+  l = sqrt_t(hx * hx + hz * hz);
+  a[0] = hx / l; a[1] = hz / l;
+}
 
 // closest points of two 2-D segments ([3P] mjc_CapsuleCapsule restated in the plane), then
 // circle-circle.  Returns up to two contacts in out[0..1].
@@ -313,240 +354,294 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
   });
 }
 
-// collision + constraint rows + reference accelerations  ([3P] mj_collision, mj_makeConstraint,
-// mj_diagApprox, mj_makeImpedance, mj_referenceConstraint)
-template <class T, class S>
-REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const PlanarGeom<T, S>& G,
-                             const LaneParams<T, S>& P, const SolParams<T>& sp, const Kin<T, S>& K,
-                             Constraints<T, S>& C) {
-  bool any = false;
-  // joint limits (hinge bodies 1..NB-1)
-  static_for<1, S::NB>([&](auto JJ) {
-    constexpr int j = JJ;
-    LimitSlot<T>& L = C.lim[j];
-    L.active = false;
-    if constexpr (S::limited[j]) {
-      T val = q[j + 2];
-      T dlo = val - T(S::range_lo[j]), dhi = T(S::range_hi[j]) - val;
-      bool lo = dlo < T(0), hi = dhi < T(0);
-      T dist = lo ? dlo : dhi;
-      L.active = lo || hi;
-      L.sigma = lo ? T(1) : T(-1);
-      T imp = impedance(sp.lim_dmin, sp.lim_dmax, sp.lim_width, abs_t(dist));
-      T R = max_t(T(1e-15), (T(1) - imp) * G.dof_invw[j] / imp);
-      L.D = T(1) / R;
-      L.aref = -sp.lim_B * (L.sigma * v[j + 2]) - sp.lim_K * imp * dist;
-      any = any || L.active;
-    }
-  });
-  // capsule ends against the floor plane z = 0
-  static_for<0, S::NG>([&](auto GG) {
-    constexpr int g = GG; constexpr int b = S::geom_body[g];
-    static_for<0, 2>([&](auto EE) {
-      constexpr int e = EE;
-      ContactSlot<T>& c = C.con[2 * g + e];
-      T lx = e == 0 ? G.e1[g][0] : G.e2[g][0], lz = e == 0 ? G.e1[g][1] : G.e2[g][1];
-      T ox, oz; rot(K.c[b], K.s[b], lx, lz, ox, oz);
-      T cx = K.A[b][0] + ox, cz = K.A[b][1] + oz;     // sphere centre rel. root anchor
-      T dist = (cz + K.zroot) - G.radius[g];
-      c.active = dist < sp.con_margin;
-      c.px = cx; c.pz = T(0.5) * dist - K.zroot;      // midpoint between the surfaces
-      c.mu = P.mu[g];
-      T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist - sp.con_margin));
-      T mu2 = c.mu * c.mu;
-      T R1 = max_t(T(1e-15), (T(1) - imp) * (G.tran_invw[b] * (T(1) + mu2)) / imp);
-      c.D = T(1) / (T(2) * mu2 * R1);
-      T vt, vn; jdot<T, S, b>(K, c.px, c.pz, v, vt, vn);
-      c.an = -sp.con_B * vn - sp.con_K * imp * (dist - sp.con_margin);
-      c.at = -sp.con_B * c.mu * vt;
-      any = any || c.active;
-    });
-  });
-  if constexpr (S::NSELF > 0) {
-    static_for<0, S::NSELF>([&](auto PP) {
-      constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
-      constexpr int ba = S::geom_body[ga], bb = S::geom_body[gb];
-      T e1x, e1z, e2x, e2z, p1[2], a1[2], p2[2], a2[2];
-      rot(K.c[ba], K.s[ba], G.e1[ga][0], G.e1[ga][1], e1x, e1z); rot(K.c[ba], K.s[ba], G.e2[ga][0], G.e2[ga][1], e2x, e2z);
-      p1[0] = K.A[ba][0] + T(0.5) * (e1x + e2x); p1[1] = K.A[ba][1] + T(0.5) * (e1z + e2z);
-      T l1 = T(0.5) * sqrt_t((e1x - e2x) * (e1x - e2x) + (e1z - e2z) * (e1z - e2z));
-      a1[0] = T(0.5) * (e1x - e2x) / l1; a1[1] = T(0.5) * (e1z - e2z) / l1;
-      rot(K.c[bb], K.s[bb], G.e1[gb][0], G.e1[gb][1], e1x, e1z); rot(K.c[bb], K.s[bb], G.e2[gb][0], G.e2[gb][1], e2x, e2z);
-      p2[0] = K.A[bb][0] + T(0.5) * (e1x + e2x); p2[1] = K.A[bb][1] + T(0.5) * (e1z + e2z);
-      T l2 = T(0.5) * sqrt_t((e1x - e2x) * (e1x - e2x) + (e1z - e2z) * (e1z - e2z));
-      a2[0] = T(0.5) * (e1x - e2x) / l2; a2[1] = T(0.5) * (e1z - e2z) / l2;
-      T cx[2], cz[2], nx[2], nz[2], dist[2]; bool hit[2];
-      capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, cx, cz, nx, nz, dist, hit);
-      static_for<0, 2>([&](auto KK) {
-        constexpr int k = KK;
-        SelfSlot<T>& s = C.self[2 * p + k];
-        s.active = hit[k] && dist[k] < sp.con_margin;
-        if (s.active) {
-          s.px = cx[k]; s.pz = cz[k]; s.nx = nx[k]; s.nz = nz[k];
-          T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist[k] - sp.con_margin));
-          T R = max_t(T(1e-15), (T(1) - imp) * (G.tran_invw[ba] + G.tran_invw[bb]) / imp);
-          s.D = T(1) / R;
-          T ta, na, tb, nb; jdot<T, S, ba>(K, s.px, s.pz, v, ta, na); jdot<T, S, bb>(K, s.px, s.pz, v, tb, nb);
-          T vel = s.nx * (tb - ta) + s.nz * (nb - na);
-          s.aref = -sp.con_B * vel - sp.con_K * imp * (dist[k] - sp.con_margin);
-          any = true;
-        } else { s.px = s.pz = s.nx = s.nz = s.D = s.aref = T(0); }
-      });
-    });
-  }
-  C.any = any;
-}
-
 #if defined(__HIP_DEVICE_COMPILE__)
 #define REX_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
 #else
 #define REX_WAVE_ANY(x) (x)
 #endif
 
+// collision + constraint rows + reference accelerations  ([3P] mj_collision, mj_makeConstraint,
+// mj_diagApprox, mj_makeImpedance, mj_referenceConstraint)
+template <class T, class S>
+REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const PlanarGeom<T, S>& G,
+                             const LaneParams<T, S>& P, const SolParams<T>& sp, const Kin<T, S>& K,
+                             Constraints<T, S>& C) {
+  unsigned lim_mask = 0, con_mask = 0;
+  // joint limits (hinge bodies 1..NB-1)
+  static_for<1, S::NB>([&](auto JJ) {
+    constexpr int j = JJ;
+    if constexpr (S::limited[j]) {
+      T val = q[j + 2];
+      T dlo = val - T(S::range_lo[j]), dhi = T(S::range_hi[j]) - val;
+      bool lo = dlo < T(0), hi = dhi < T(0);
+      T dist = lo ? dlo : dhi;
+      if (lo || hi) lim_mask |= 1u << j;
+      T sg = lo ? T(1) : T(-1);
+      T imp = impedance(sp.lim_dmin, sp.lim_dmax, sp.lim_width, abs_t(dist));
+      // R = max(MINVAL, (1-imp)/imp * dof_invweight0);  D = 1/R
+      C.lD[j] = imp * rcp_t(max_t(T(1e-15), (T(1) - imp) * G.dof_invw[j]));
+      C.lsig[j] = sg;
+      C.laref[j] = -sp.lim_B * (sg * v[j + 2]) - sp.lim_K * imp * dist;
+    }
+  });
+  // capsule ends against the floor plane z = 0
+  static_for<0, S::NG>([&](auto GG) {
+    constexpr int g = GG; constexpr int b = S::geom_body[g];
+    static_for<0, 2>([&](auto EE) {
+      constexpr int e = EE; constexpr int k = 2 * g + e;
+      T lx = e == 0 ? G.e1[g][0] : G.e2[g][0], lz = e == 0 ? G.e1[g][1] : G.e2[g][1];
+      T ox, oz; rot(K.c[b], K.s[b], lx, lz, ox, oz);
+      T cx = K.A[b][0] + ox, cz = K.A[b][1] + oz;     // sphere centre rel. root anchor
+      T dist = (cz + K.zroot) - G.radius[g];
+      bool act = dist < sp.con_margin;
+      if (act) con_mask |= 1u << k;
+      C.px[k] = cx; C.pz[k] = T(0.5) * dist - K.zroot;   // midpoint between the surfaces
+      if (REX_WAVE_ANY(act)) {
+        T mu = P.mu[g], mu2 = mu * mu;
+        T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist - sp.con_margin));
+        // R1 = (1-imp)/imp * tran*(1+mu^2) ; Rpy = 2 mu^2 R1 ; D = 1/Rpy
+        C.D[k] = imp * rcp_t(max_t(T(1e-15), T(2) * mu2 * (T(1) - imp) * (G.tran_invw[b] * (T(1) + mu2))));
+        T vt, vn; jdot<T, S, b>(K, C.px[k], C.pz[k], v, vt, vn);
+        C.an[k] = -sp.con_B * vn - sp.con_K * imp * (dist - sp.con_margin);
+        C.at[k] = -sp.con_B * mu * vt;
+      } else { C.D[k] = T(0); C.an[k] = T(0); C.at[k] = T(0); }
+    });
+  });
+  C.lim_mask = lim_mask; C.con_mask = con_mask;
+  // bounding-circle cull of the capsule-capsule self pairs
+  bool sp_any = false;
+  if constexpr (S::NSELF > 0) {
+    static_for<0, S::NSELF>([&](auto PP) {
+      constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
+      constexpr int ba = S::geom_body[ga], bb = S::geom_body[gb];
+      T ax, az, bx, bz;
+      rot(K.c[ba], K.s[ba], T(0.5) * (G.e1[ga][0] + G.e2[ga][0]), T(0.5) * (G.e1[ga][1] + G.e2[ga][1]), ax, az);
+      rot(K.c[bb], K.s[bb], T(0.5) * (G.e1[gb][0] + G.e2[gb][0]), T(0.5) * (G.e1[gb][1] + G.e2[gb][1]), bx, bz);
+      T dx = (K.A[bb][0] + bx) - (K.A[ba][0] + ax), dz = (K.A[bb][1] + bz) - (K.A[ba][1] + az);
+      T la2 = (G.e1[ga][0] - G.e2[ga][0]) * (G.e1[ga][0] - G.e2[ga][0]) + (G.e1[ga][1] - G.e2[ga][1]) * (G.e1[ga][1] - G.e2[ga][1]);
+      T lb2 = (G.e1[gb][0] - G.e2[gb][0]) * (G.e1[gb][0] - G.e2[gb][0]) + (G.e1[gb][1] - G.e2[gb][1]) * (G.e1[gb][1] - G.e2[gb][1]);
+      T reach = T(0.5) * (sqrt_t(la2) + sqrt_t(lb2)) + G.radius[ga] + G.radius[gb] + sp.con_margin;
+      sp_any = sp_any || (dx * dx + dz * dz <= reach * reach);
+    });
+  }
+  C.self_possible = sp_any;
+  C.any = (lim_mask | con_mask) != 0u;
+}
+
+template <class T, class S>
+REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const SolParams<T>& sp, const Kin<T, S>& K,
+                           SelfRows<T, S>& R) {
+  unsigned mask = 0;
+  if constexpr (S::NSELF > 0) {
+    static_for<0, S::NSELF>([&](auto PP) {
+      constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
+      constexpr int ba = S::geom_body[ga], bb = S::geom_body[gb];
+      T p1[2], a1[2], p2[2], a2[2], l1, l2;
+      capsule_pose<T, S, ga>(K, G, p1, a1, l1); capsule_pose<T, S, gb>(K, G, p2, a2, l2);
+      T cx[2], cz[2], nx[2], nz[2], dist[2]; bool hit[2];
+      capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, cx, cz, nx, nz, dist, hit);
+      static_for<0, 2>([&](auto KK) {
+        constexpr int k = KK; constexpr int r = 2 * p + k;
+        bool act = hit[k] && dist[k] < sp.con_margin;
+        if (act) {
+          mask |= 1u << r;
+          R.px[r] = cx[k]; R.pz[r] = cz[k]; R.nx[r] = nx[k]; R.nz[r] = nz[k];
+          T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist[k] - sp.con_margin));
+          R.D[r] = imp / max_t(T(1e-15), (T(1) - imp) * (G.tran_invw[ba] + G.tran_invw[bb]));
+          T ta, na, tb, nb; jdot<T, S, ba>(K, R.px[r], R.pz[r], v, ta, na); jdot<T, S, bb>(K, R.px[r], R.pz[r], v, tb, nb);
+          T vel = R.nx[r] * (tb - ta) + R.nz[r] * (nb - na);
+          R.aref[r] = -sp.con_B * vel - sp.con_K * imp * (dist[k] - sp.con_margin);
+        } else { R.px[r] = R.pz[r] = R.nx[r] = R.nz[r] = R.D[r] = R.aref[r] = T(0); }
+      });
+    });
+  }
+  R.mask = mask;
+}
+
 struct SolveStats { int iters; bool capped; };
 
 // Primal Newton solve of   min_a 0.5 (a-a0)^T M (a-a0) + sum_rows 0.5 D min(0, J a - aref)^2
 // ([3P] engine_solver, Newton, pyramidal cones): exact Hessian M + J^T D_active J with the tree
 // sparsity of M, L^T D L factorisation, exact line search on the piecewise-quadratic 1-D cost.
-// All lanes of a wave iterate together; a lane that has converged keeps alpha = 0.
-template <class T, class S, int MAXIT = 24>
+// All lanes of a wave iterate together; a lane that has converged keeps alpha = 0.  Rows are
+// re-derived from (contact point, anchors) on the fly and slots no lane of the wave touches are
+// skipped with a wave-uniform branch: the solver's live state is M, H, g and 5 floats per slot.
+template <class T, class S, bool SELF, int MAXIT = 24>
 REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
-                               const Kin<T, S>& K, const Constraints<T, S>& C, const SolParams<T>& sp, T (&qacc)[S::NV]) {
+                               const Kin<T, S>& K, const Constraints<T, S>& C, const SelfRows<T, S>& R,
+                               const LaneParams<T, S>& P, T (&qacc)[S::NV]) {
   static_for<0, S::NV>([&](auto II) { qacc[II] = qacc_smooth[II]; });
   SolveStats st{0, false};
   // stop when the force residual |M a - f - J^T f_c| is at rounding level relative to the forces
-  // that balance in it (the piecewise-quadratic cost makes Newton exact once the active set is
-  // right, so the residual drops from O(1) to rounding in one step)
-  const T tol2 = sizeof(T) == 4 ? T(1e-10) : T(1e-24);
-  bool lane_done = !C.any;
+  // that balance in it (the piecewise-quadratic cost makes Newton exact once the active set is right)
+  const T tol2 = sizeof(T) == 4 ? T(1e-9) : T(1e-24);
+  const T stag = sizeof(T) == 4 ? T(1e-6) : T(1e-15);
+  // previous iteration's active edges: if a Newton step lands in the region it was computed for,
+  // every row kept its sign along the step (rows are linear in alpha), the cost was exactly
+  // quadratic there and the step was its exact minimiser -> converged, independent of rounding
+  unsigned p_lim = ~0u, p_e1 = ~0u, p_e2 = ~0u, p_e3 = ~0u, p_self = ~0u;
+  bool lane_done = !(C.any || (SELF && R.mask != 0u));
+  constexpr int NC = 2 * S::NG;
   for (int it = 0; it < MAXIT; ++it) {
     if (!REX_WAVE_ANY(!lane_done)) break;
-    T g[S::NV], Ma[S::NV], H[S::NV][S::NV];
+    T cpx[NC], cpz[NC];   // per-iteration opaque copies of the contact points (see opaque())
+    static_for<0, NC>([&](auto KK) { constexpr int k = KK; cpx[k] = C.px[k]; cpz[k] = C.pz[k]; opaque(cpx[k]); opaque(cpz[k]); });
+    // ---- pass 1: gradient and active edges --------------------------------------------------
+    T g[S::NV], Ma[S::NV];
     sym_matvec<T, S>(M, qacc, Ma);
     T fref = T(0);
-    static_for<0, S::NV>([&](auto II) {
-      constexpr int i = II; g[i] = Ma[i] - qfrc_smooth[i]; fref += Ma[i] * Ma[i] + qfrc_smooth[i] * qfrc_smooth[i];
-      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] = M[i][j]; });
-    });
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] = Ma[i] - qfrc_smooth[i]; fref += Ma[i] * Ma[i] + qfrc_smooth[i] * qfrc_smooth[i]; });
+    unsigned lim_on = 0, e1 = 0, e2 = 0, e3 = 0, self_on = 0;
     static_for<1, S::NB>([&](auto JJ) {
       constexpr int j = JJ;
       if constexpr (S::limited[j]) {
-        const LimitSlot<T>& L = C.lim[j];
-        T jar = L.sigma * qacc[j + 2] - L.aref;
-        bool on = L.active && jar < T(0);
-        T f = on ? -L.D * jar : T(0);
-        g[j + 2] -= L.sigma * f;
-        H[j + 2][j + 2] += on ? L.D : T(0);
+        T jar = C.lsig[j] * qacc[j + 2] - C.laref[j];
+        bool on = ((C.lim_mask >> j) & 1u) && jar < T(0);
+        if (on) lim_on |= 1u << j;
+        g[j + 2] += on ? C.lsig[j] * C.lD[j] * jar : T(0);
       }
     });
     static_for<0, S::NG>([&](auto GG) {
       constexpr int gg = GG; constexpr int b = S::geom_body[gg];
       static_for<0, 2>([&](auto EE) {
-        const ContactSlot<T>& c = C.con[2 * gg + EE];
-        if (REX_WAVE_ANY(c.active)) {
-          T jt, jn; jdot<T, S, b>(K, c.px, c.pz, qacc, jt, jn);
-          T r1 = jn + c.mu * jt - (c.an + c.at), r2 = jn - c.mu * jt - (c.an - c.at), r3 = jn - c.an;
-          T s1 = (c.active && r1 < T(0)) ? T(1) : T(0), s2 = (c.active && r2 < T(0)) ? T(1) : T(0);
-          T s3 = (c.active && r3 < T(0)) ? T(1) : T(0);
-          T f1 = -c.D * r1 * s1, f2 = -c.D * r2 * s2, f3 = -c.D * r3 * s3;
-          jt_accum<T, S, b>(K, c.px, c.pz, -(c.mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
-          T mu2 = c.mu * c.mu;
-          hess_accum<T, S, b>(K, c.px, c.pz, c.D * mu2 * (s1 + s2), c.D * c.mu * (s1 - s2), c.D * (s1 + s2 + T(2) * s3), H);
+        constexpr int k = 2 * gg + EE;
+        const bool act = (C.con_mask >> k) & 1u;
+        if (REX_WAVE_ANY(act)) {
+          const T mu = P.mu[gg];
+          T jt, jn; jdot<T, S, b>(K, cpx[k], cpz[k], qacc, jt, jn);
+          T r1 = jn + mu * jt - (C.an[k] + C.at[k]), r2 = jn - mu * jt - (C.an[k] - C.at[k]), r3 = jn - C.an[k];
+          bool s1 = act && r1 < T(0), s2 = act && r2 < T(0), s3 = act && r3 < T(0);
+          if (s1) e1 |= 1u << k; if (s2) e2 |= 1u << k; if (s3) e3 |= 1u << k;
+          T f1 = s1 ? -C.D[k] * r1 : T(0), f2 = s2 ? -C.D[k] * r2 : T(0), f3 = s3 ? -C.D[k] * r3 : T(0);
+          jt_accum<T, S, b>(K, cpx[k], cpz[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
         }
       });
     });
-    if constexpr (S::NSELF > 0) {
+    if constexpr (SELF && S::NSELF > 0) {
       static_for<0, 2 * S::NSELF>([&](auto PP) {
         constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
-        const SelfSlot<T>& s = C.self[p];
-        if (REX_WAVE_ANY(s.active)) {
-          T ta, na, tb, nb; jdot<T, S, ba>(K, s.px, s.pz, qacc, ta, na); jdot<T, S, bb>(K, s.px, s.pz, qacc, tb, nb);
-          T jar = s.nx * (tb - ta) + s.nz * (nb - na) - s.aref;
-          bool on = s.active && jar < T(0);
-          T f = on ? -s.D * jar : T(0);
-          jt_accum<T, S, bb>(K, s.px, s.pz, -s.nx * f, -s.nz * f, g);
-          jt_accum<T, S, ba>(K, s.px, s.pz, s.nx * f, s.nz * f, g);
-          // row = n.(J_b - J_a): build it explicitly, rank-1 update on the (dense) root path union
-          T row[S::NV];
-          static_for<0, S::NV>([&](auto II) { row[II] = T(0); });
-          jt_accum<T, S, bb>(K, s.px, s.pz, s.nx, s.nz, row); jt_accum<T, S, ba>(K, s.px, s.pz, -s.nx, -s.nz, row);
-          T d = on ? s.D : T(0);
-          static_for<0, S::NV>([&](auto AA) { constexpr int a = AA;
-            static_for<0, a + 1>([&](auto BB) { constexpr int bq = BB; if constexpr (dof_coupled<S>(a, bq)) H[a][bq] += d * row[a] * row[bq]; }); });
+        const bool act = (R.mask >> p) & 1u;
+        if (REX_WAVE_ANY(act)) {
+          T ta, na, tb, nb; jdot<T, S, ba>(K, R.px[p], R.pz[p], qacc, ta, na); jdot<T, S, bb>(K, R.px[p], R.pz[p], qacc, tb, nb);
+          T jar = R.nx[p] * (tb - ta) + R.nz[p] * (nb - na) - R.aref[p];
+          bool on = act && jar < T(0);
+          if (on) self_on |= 1u << p;
+          T f = on ? -R.D[p] * jar : T(0);
+          jt_accum<T, S, bb>(K, R.px[p], R.pz[p], -R.nx[p] * f, -R.nz[p] * f, g);
+          jt_accum<T, S, ba>(K, R.px[p], R.pz[p], R.nx[p] * f, R.nz[p] * f, g);
         }
       });
     }
     T gn = T(0);
     static_for<0, S::NV>([&](auto II) { gn += g[II] * g[II]; });
-    lane_done = lane_done || !(gn > tol2 * fref);   // NaN counts as done
+#if defined(REX_DEBUG_SOLVER) && !defined(__HIP_DEVICE_COMPILE__)
+    if (it >= 12) printf("  it %d gn/fref %.3e con_mask %x e1 %x e2 %x e3 %x lim %x\n", it, double(gn / fref), C.con_mask, e1, e2, e3, lim_on);
+#endif
+    const bool same_set = lim_on == p_lim && e1 == p_e1 && e2 == p_e2 && e3 == p_e3 && self_on == p_self;
+    p_lim = lim_on; p_e1 = e1; p_e2 = e2; p_e3 = e3; p_self = self_on;
+    lane_done = lane_done || same_set || !(gn > tol2 * fref);   // NaN counts as done
     if (!REX_WAVE_ANY(!lane_done)) break;
-    // search = -H^-1 g
-    ldl_factor<T, S>(H);
-    T sr[S::NV];
-    static_for<0, S::NV>([&](auto II) { sr[II] = -g[II]; });
-    ldl_solve<T, S>(H, sr);
-    // line search: phi(alpha) = quad + sum rows
-    T Ms[S::NV];
-    sym_matvec<T, S>(M, sr, Ms);
-    T q1 = T(0), q2 = T(0);   // phi'(0) gauss part, half curvature
-    static_for<0, S::NV>([&](auto II) { q1 += sr[II] * (Ma[II] - qfrc_smooth[II]); q2 += sr[II] * Ms[II]; });
-    // per-row (jar, jv) pairs
-    T lr[S::NB], lv[S::NB];
+    // ---- pass 2: Hessian of the current active set, Newton direction ------------------------
+    T H[S::NV][S::NV];
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] = M[i][j]; }); });
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-      if constexpr (S::limited[j]) { lr[j] = C.lim[j].sigma * qacc[j + 2] - C.lim[j].aref; lv[j] = C.lim[j].sigma * sr[j + 2]; } });
-    T cr[2 * S::NG][3], cv[2 * S::NG][3];
+      if constexpr (S::limited[j]) H[j + 2][j + 2] += ((lim_on >> j) & 1u) ? C.lD[j] : T(0); });
     static_for<0, S::NG>([&](auto GG) {
       constexpr int gg = GG; constexpr int b = S::geom_body[gg];
       static_for<0, 2>([&](auto EE) {
         constexpr int k = 2 * gg + EE;
-        const ContactSlot<T>& c = C.con[k];
-        T jt, jn, vt, vn; jdot<T, S, b>(K, c.px, c.pz, qacc, jt, jn); jdot<T, S, b>(K, c.px, c.pz, sr, vt, vn);
-        cr[k][0] = jn + c.mu * jt - (c.an + c.at); cr[k][1] = jn - c.mu * jt - (c.an - c.at); cr[k][2] = jn - c.an;
-        cv[k][0] = vn + c.mu * vt; cv[k][1] = vn - c.mu * vt; cv[k][2] = vn;
+        const unsigned bit = 1u << k;
+        if (REX_WAVE_ANY(((e1 | e2 | e3) & bit) != 0u)) {
+          const T mu = P.mu[gg];
+          T s1 = (e1 & bit) ? T(1) : T(0), s2 = (e2 & bit) ? T(1) : T(0), s3 = (e3 & bit) ? T(1) : T(0);
+          hess_accum<T, S, b>(K, cpx[k], cpz[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), H);
+        }
       });
     });
-    T sfr[S::NSELF > 0 ? 2 * S::NSELF : 1], sfv[S::NSELF > 0 ? 2 * S::NSELF : 1];
-    if constexpr (S::NSELF > 0) {
+    if constexpr (SELF && S::NSELF > 0) {
       static_for<0, 2 * S::NSELF>([&](auto PP) {
         constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
-        const SelfSlot<T>& s = C.self[p];
-        T ta, na, tb, nb; jdot<T, S, ba>(K, s.px, s.pz, qacc, ta, na); jdot<T, S, bb>(K, s.px, s.pz, qacc, tb, nb);
-        sfr[p] = s.nx * (tb - ta) + s.nz * (nb - na) - s.aref;
-        jdot<T, S, ba>(K, s.px, s.pz, sr, ta, na); jdot<T, S, bb>(K, s.px, s.pz, sr, tb, nb);
-        sfv[p] = s.nx * (tb - ta) + s.nz * (nb - na);
+        if (REX_WAVE_ANY(((self_on >> p) & 1u) != 0u)) {
+          // row = n.(J_b - J_a): built explicitly, rank-1 update (hopper is a chain: H is dense)
+          T row[S::NV];
+          static_for<0, S::NV>([&](auto II) { row[II] = T(0); });
+          jt_accum<T, S, bb>(K, R.px[p], R.pz[p], R.nx[p], R.nz[p], row); jt_accum<T, S, ba>(K, R.px[p], R.pz[p], -R.nx[p], -R.nz[p], row);
+          T d = ((self_on >> p) & 1u) ? R.D[p] : T(0);
+          static_for<0, S::NV>([&](auto AA) { constexpr int a = AA;
+            static_for<0, a + 1>([&](auto BB) { constexpr int bq = BB; if constexpr (dof_coupled<S>(a, bq)) H[a][bq] += d * row[a] * row[bq]; }); });
+        }
       });
     }
+    ldl_factor<T, S>(H);
+    T sr[S::NV];
+    static_for<0, S::NV>([&](auto II) { sr[II] = -g[II]; });
+    ldl_solve<T, S>(H, sr);
+    // ---- exact line search on phi(alpha); phi'(0) = g.sr, Gauss curvature sr^T M sr ----------
+    T Ms[S::NV];
+    sym_matvec<T, S>(M, sr, Ms);
+    T q1 = T(0), q2 = T(0), d0 = T(0);
+    static_for<0, S::NV>([&](auto II) { q1 += sr[II] * (Ma[II] - qfrc_smooth[II]); q2 += sr[II] * Ms[II]; d0 += sr[II] * g[II]; });
     auto deriv = [&](T a, T& d1, T& d2) {
+      static_for<0, NC>([&](auto KK) { constexpr int k = KK; opaque(cpx[k]); opaque(cpz[k]); });
       d1 = q1 + a * q2; d2 = q2;
       static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-        if constexpr (S::limited[j]) { T x = lr[j] + a * lv[j]; bool on = C.lim[j].active && x < T(0);
-          T dd = on ? C.lim[j].D : T(0); d1 += dd * x * lv[j]; d2 += dd * lv[j] * lv[j]; } });
-      static_for<0, 2 * S::NG>([&](auto KK) { constexpr int k = KK; const ContactSlot<T>& c = C.con[k];
-        static_for<0, 3>([&](auto RR) { constexpr int r = RR;
-          T x = cr[k][r] + a * cv[k][r]; bool on = c.active && x < T(0);
-          T dd = on ? (r == 2 ? T(2) * c.D : c.D) : T(0); d1 += dd * x * cv[k][r]; d2 += dd * cv[k][r] * cv[k][r]; }); });
-      if constexpr (S::NSELF > 0) static_for<0, 2 * S::NSELF>([&](auto PP) { constexpr int p = PP;
-        T x = sfr[p] + a * sfv[p]; bool on = C.self[p].active && x < T(0);
-        T dd = on ? C.self[p].D : T(0); d1 += dd * x * sfv[p]; d2 += dd * sfv[p] * sfv[p]; });
+        if constexpr (S::limited[j]) {
+          T lr = C.lsig[j] * qacc[j + 2] - C.laref[j], lv = C.lsig[j] * sr[j + 2];
+          T x = lr + a * lv; bool on = ((C.lim_mask >> j) & 1u) && x < T(0);
+          T dd = on ? C.lD[j] : T(0); d1 += dd * x * lv; d2 += dd * lv * lv; } });
+      static_for<0, S::NG>([&](auto GG) {
+        constexpr int gg = GG; constexpr int b = S::geom_body[gg];
+        static_for<0, 2>([&](auto EE) {
+          constexpr int k = 2 * gg + EE;
+          const bool act = (C.con_mask >> k) & 1u;
+          if (REX_WAVE_ANY(act)) {
+            const T mu = P.mu[gg];
+            T jt, jn, vt, vn; jdot2<T, S, b>(K, cpx[k], cpz[k], qacc, sr, jt, jn, vt, vn);
+            T r0 = jn + mu * jt - (C.an[k] + C.at[k]), r1 = jn - mu * jt - (C.an[k] - C.at[k]), r2 = jn - C.an[k];
+            T v0 = vn + mu * vt, v1 = vn - mu * vt, v2 = vn;
+            T x0 = r0 + a * v0, x1 = r1 + a * v1, x2 = r2 + a * v2;
+            T w0 = (act && x0 < T(0)) ? C.D[k] : T(0), w1 = (act && x1 < T(0)) ? C.D[k] : T(0), w2 = (act && x2 < T(0)) ? T(2) * C.D[k] : T(0);
+            d1 += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2;
+            d2 += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2;
+          }
+        });
+      });
+      if constexpr (SELF && S::NSELF > 0) static_for<0, 2 * S::NSELF>([&](auto PP) {
+        constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
+        const bool act = (R.mask >> p) & 1u;
+        if (REX_WAVE_ANY(act)) {
+          T ta, na, tb, nb, ua, ma_, ub, mb_;
+          jdot2<T, S, ba>(K, R.px[p], R.pz[p], qacc, sr, ta, na, ua, ma_); jdot2<T, S, bb>(K, R.px[p], R.pz[p], qacc, sr, tb, nb, ub, mb_);
+          T r = R.nx[p] * (tb - ta) + R.nz[p] * (nb - na) - R.aref[p], vv = R.nx[p] * (ub - ua) + R.nz[p] * (mb_ - ma_);
+          T x = r + a * vv; T dd = (act && x < T(0)) ? R.D[p] : T(0);
+          d1 += dd * x * vv; d2 += dd * vv * vv;
+        }
+      });
     };
-    // phi' is piecewise linear and increasing: safeguarded Newton from alpha = 0
-    T a = T(0), lo = T(0), hi = T(-1), d1, d2;
+    // the Newton step itself (alpha = 1) is exact whenever the active set does not change along it
+    const T d1ref = abs_t(d0) * T(sizeof(T) == 4 ? 1e-5 : 1e-13) + T(1e-30);
+    T a = T(1), lo = T(0), hi = T(-1), d1, d2;
     deriv(a, d1, d2);
-    const T d1ref = abs_t(d1) * T(sizeof(T) == 4 ? 1e-5 : 1e-13) + T(1e-30);
-    bool ls_done = lane_done;
-    for (int ls = 0; ls < 12; ++ls) {
+    bool ls_done = lane_done || abs_t(d1) <= d1ref;
+    for (int ls = 0; ls < 16; ++ls) {   // phi' is piecewise linear and increasing: safeguarded Newton
       if (!REX_WAVE_ANY(!ls_done)) break;
       if (d1 < T(0)) lo = a; else hi = a;
-      T an = a - d1 / d2;
-      if (hi >= T(0) && (an <= lo || an >= hi)) an = T(0.5) * (lo + hi);
-      an = max_t(an, lo);
+      T an_ = a - d1 / d2;
+      if (hi >= T(0) && (an_ <= lo || an_ >= hi)) an_ = T(0.5) * (lo + hi);
+      an_ = max_t(an_, lo);
       T prev = a;
-      a = ls_done ? a : an;
+      a = ls_done ? a : an_;
       deriv(a, d1, d2);
       ls_done = ls_done || abs_t(d1) <= d1ref || a == prev;
     }
     a = lane_done ? T(0) : a;
-    static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; });
+    T amax = T(0), smax = T(0);
+    static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; amax = max_t(amax, abs_t(qacc[II])); smax = max_t(smax, abs_t(a * sr[II])); });
+#if defined(REX_DEBUG_SOLVER) && !defined(__HIP_DEVICE_COMPILE__)
+    if (it >= 12) printf("     alpha %.6g smax %.3e amax %.3e d1 %.3e d0 %.3e\n", double(a), double(smax), double(amax), double(d1), double(d0));
+#endif
+    lane_done = lane_done || smax <= stag * (T(1) + amax);   // stagnation at rounding level
     st.iters = it + 1;
     if (it == MAXIT - 1) st.capped = REX_WAVE_ANY(!lane_done);
   }
@@ -559,24 +654,39 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
                           const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV]) {
   Kin<T, S> K;
   kinematics<T, S>(q, G, K);
-  T bias[S::NV], f[S::NV], a0[S::NV];
-  mass_and_bias<T, S>(v, G, P, K, M, bias);
-  f[0] = -bias[0]; f[1] = -bias[1]; f[2] = -bias[2];
-  static_for<1, S::NB>([&](auto JJ) {
-    constexpr int j = JJ;
-    T c = min_t(max_t(ctrl[j - 1], T(-1)), T(1));   // ctrlrange -1..1 on every motor of the three XMLs
-    f[j + 2] = -G.damping[j] * v[j + 2] - G.stiffness[j] * q[j + 2] - bias[j + 2] + T(S::gear[j - 1]) * c;
-  });
-  T L[S::NV][S::NV];
-  static_for<0, S::NV>([&](auto II) { constexpr int i = II; a0[i] = f[i];
-    static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) L[i][j] = M[i][j]; }); });
-  ldl_factor<T, S>(L);
-  ldl_solve<T, S>(L, a0);
+  T f[S::NV], a0[S::NV];
+  {
+    T bias[S::NV];
+    mass_and_bias<T, S>(v, G, P, K, M, bias);
+    f[0] = -bias[0]; f[1] = -bias[1]; f[2] = -bias[2];
+    static_for<1, S::NB>([&](auto JJ) {
+      constexpr int j = JJ;
+      T c = min_t(max_t(ctrl[j - 1], T(-1)), T(1));   // ctrlrange -1..1 on every motor of the three XMLs
+      f[j + 2] = -G.damping[j] * v[j + 2] - G.stiffness[j] * q[j + 2] - bias[j + 2] + T(S::gear[j - 1]) * c;
+    });
+  }
+  {
+    T L[S::NV][S::NV];
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II; a0[i] = f[i];
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) L[i][j] = M[i][j]; }); });
+    ldl_factor<T, S>(L);
+    ldl_solve<T, S>(L, a0);
+  }
   Constraints<T, S> C;
   make_constraints<T, S>(q, v, G, P, sp, K, C);
   SolveStats st{0, false};
-  if (REX_WAVE_ANY(C.any)) st = solve_newton<T, S>(M, f, a0, K, C, sp, qacc);
-  else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+  bool self_path = false;
+  if constexpr (S::NSELF > 0) self_path = REX_WAVE_ANY(C.self_possible);
+  if (self_path) {   // rare: a capsule-capsule self contact may exist somewhere in this wave
+    SelfRows<T, S> R;
+    make_self_rows<T, S>(v, G, sp, K, R);
+    st = solve_newton<T, S, true>(M, f, a0, K, C, R, P, qacc);
+  } else if (REX_WAVE_ANY(C.any)) {
+    SelfRows<T, S> R; R.mask = 0u;
+    st = solve_newton<T, S, false>(M, f, a0, K, C, R, P, qacc);
+  } else {
+    static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+  }
   return st;
 }
 
