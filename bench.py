@@ -27,7 +27,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ENV_ID = "RandomHopper-v0"
 BATCH_PER_GPU = 32768
-BYTES_PER_ENV_STEP = 173          # read (6+6+3+4)*4 = 76, write (6+6+11+1)*4+1 = 97
+# algorithmic bytes per env-step = read (qpos,qvel,action,xi) + write (qpos,qvel,obs,reward,done)
+BYTES_PER_ENV_STEP = {"RandomHopper-v0": 173, "RandomWalker2d-v0": 293, "RandomHalfCheetah-v0": 273,
+                      "RandomHalfCheetahNoisy-v0": 273, "RandomCartPole-v0": 73}
+KERNEL_NAME = {"RandomHopper-v0": "planar_step_kernel<HopperSpec>", "RandomWalker2d-v0": "planar_step_kernel<Walker2dSpec>",
+               "RandomHalfCheetah-v0": "planar_step_kernel<HalfCheetahSpec>",
+               "RandomHalfCheetahNoisy-v0": "planar_step_kernel<HalfCheetahSpec>", "RandomCartPole-v0": "cartpole_step_kernel"}
+METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 NOMINAL = [3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 5.0893800988154645]
 
@@ -68,24 +74,19 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     import __graft_entry__ as graft
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from random_envs_amd import sharding
+    rank, local_rank, world = sharding.dist_env()
     torch.cuda.set_device(local_rank)
     if rank == 0:
         graft.build()
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
-        dist.barrier()
+    sharding.init("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; no-op at N=1
+    sharding.barrier()
     import random_envs_amd as rex
 
     B = args.batch
-    env = rex.make(args.env, batch=B, device=local_rank, seed=0, env_offset=rank * B)   # index-sharded batch
+    env_offset, _ = sharding.shard(B, rank)                    # index-sharded batch, weak scaling
+    env = rex.make(args.env, batch=B, device=local_rank, seed=0, env_offset=env_offset)
     nom = torch.tensor(env.original_task)
     env.set_dr_distribution("uniform", torch.stack([0.9 * nom, 1.1 * nom], 1).flatten().tolist())
     env.set_dr_training(True)
@@ -93,11 +94,9 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     nact = 16
     actions = [(torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1).cuda(local_rank).contiguous() for _ in range(nact)]
-    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        sharding.barrier()
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
@@ -112,19 +111,15 @@ def main():
     kernel_ms = env.read_timing()
     env.enable_timing(False)
 
-    # the only data-path-adjacent collective: reduce the step counter (and the contract's max time)
-    counter += args.steps * B
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(counter, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_steps = int(counter.item()); elapsed = float(tmax.item())
+    # the only collectives of the path: SUM of the step counter, MAX of the elapsed time
+    total_steps, elapsed = sharding.reduce_counter_and_time(args.steps * B, elapsed, torch.device("cuda", local_rank))
     counters = env.counters()
 
     if rank == 0:
         value = total_steps / elapsed
         kavg_ms = float(kernel_ms.mean()) if len(kernel_ms) else float("nan")
-        achieved = BYTES_PER_ENV_STEP * B / (kavg_ms * 1e-3) / 1e9 if kavg_ms == kavg_ms else None
+        bytes_step = BYTES_PER_ENV_STEP[args.env]
+        achieved = bytes_step * B / (kavg_ms * 1e-3) / 1e9 if kavg_ms == kavg_ms else None
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass result (separate rocprofv3 --pmc runs)
         if os.path.exists(tp):
@@ -133,7 +128,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env-steps/sec at batch 32768, RandomHopper-v0", "value": value, "unit": "env-steps/s",
+            "metric": METRIC, "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, batch %d per GPU, uniform DR over 4 link masses (nominal +-10%%), "
@@ -141,18 +136,16 @@ def main():
                        "global_batch": B * world, "parallelism": "index-sharded envs x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "planar_step_kernel<HopperSpec>", "kernel_avg_ms": kavg_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * B,
-                         "note": "latency/VALU-bound by construction: 16 forward-dynamics solves per 173 B"},
+                         "kernel": KERNEL_NAME[args.env], "kernel_avg_ms": kavg_ms,
+                         "algorithmic_bytes_per_launch": bytes_step * B, "bytes_per_env_step": bytes_step,
+                         "note": "VALU-issue/latency-bound by construction (16 forward-dynamics solves per 173 B for hopper); HBM fraction reported because the metric asks for it"},
             "solver_capped_waves": counters["solver_capped"], "nonfinite_lanes": counters["nonfinite"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_sample_steps)
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    sharding.shutdown()
 
 
 if __name__ == "__main__":

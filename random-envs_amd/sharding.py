@@ -1,0 +1,64 @@
+"""Multi-GPU plumbing: one process per GPU, the env batch sharded by index, no data-path collective.
+
+The reference has nothing distributed; envs are independent objects, so a
+batch shards trivially: rank r owns the contiguous global indices [r*B, (r+1)*B).  RNG streams are
+keyed by GLOBAL env index inside the kernels, so results do not depend on the sharding.  The only
+collectives are a SUM of the step counter and a MAX of the elapsed time (RCCL over xGMI via
+torch.distributed backend "nccl"; "gloo" on CPU for tests)."""
+import os
+
+
+def dist_env():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard(batch_per_rank, rank):
+    """(env_offset, batch) of this rank under weak scaling."""
+    return rank * batch_per_rank, batch_per_rank
+
+
+def shard_strong(global_batch, rank, world):
+    """(env_offset, batch) of this rank when a fixed global batch is split (remainder to low ranks)."""
+    q, r = divmod(global_batch, world)
+    b = q + (1 if rank < r else 0)
+    off = rank * q + min(rank, r)
+    return off, b
+
+
+def init(backend, device=None):
+    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+    return rank, local_rank, world
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_counter_and_time(steps_done, elapsed_s, device):
+    """SUM of env-steps over ranks and MAX of the elapsed time (the only collectives of the path)."""
+    import torch
+    import torch.distributed as dist
+    c = torch.tensor([int(steps_done)], dtype=torch.int64, device=device)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(c.item()), float(t.item())
+
+
+def shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

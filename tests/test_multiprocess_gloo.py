@@ -1,0 +1,63 @@
+"""N > 1 launch path on CPU: world_size 2, gloo.  Covers the sharding arithmetic and the only
+collectives the path uses (SUM of the step counter, MAX of the elapsed time)."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch
+from random_envs_amd import sharding
+rank, local_rank, world = sharding.init("gloo")
+assert world == 2
+off, b = sharding.shard(32768, rank)
+assert (off, b) == (rank * 32768, 32768)
+so, sb = sharding.shard_strong(32769, rank, world)
+steps = 10 * b + rank                      # each rank "did" a different amount of work
+total, tmax = sharding.reduce_counter_and_time(steps, 1.0 + rank, torch.device("cpu"))
+sharding.barrier()
+print(json.dumps(dict(rank=rank, off=off, so=so, sb=sb, total=total, tmax=tmax)), flush=True)
+sharding.shutdown()
+"""
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_rank_gloo_sharding_and_counter(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert [d["off"] for d in outs] == [0, 32768]
+    assert all(d["total"] == 10 * 32768 * 2 + 1 for d in outs)          # SUM over ranks
+    assert all(d["tmax"] == 2.0 for d in outs)                          # MAX over ranks
+    # strong split covers the global batch exactly once
+    assert outs[0]["so"] == 0 and outs[1]["so"] == outs[0]["sb"] and outs[0]["sb"] + outs[1]["sb"] == 32769
+
+
+def test_shard_strong_partition():
+    from random_envs_amd import sharding
+    for world in (1, 2, 3, 4, 8):
+        cover = []
+        for r in range(world):
+            off, b = sharding.shard_strong(32768 + 5, r, world)
+            cover += list(range(off, off + b))
+        assert cover == list(range(32768 + 5))
