@@ -36,6 +36,29 @@ REX_HD double abs_t(double a) { return fabs(a); }
 template <class T> REX_HD T min_t(T a, T b) { return a < b ? a : b; }
 template <class T> REX_HD T max_t(T a, T b) { return a > b ? a : b; }
 
+// Optimisation barrier: tells the compiler the value may have changed.  Used at the top of the
+// solver loops so that LLVM's loop-invariant code motion does not hoist every lever arm and
+// Jacobian entry of every contact slot out of the loops (it does, speculatively, and the ~200
+// hoisted values then spill to scratch memory: 590 MB of HBM writes per launch were measured).
+template <class T> REX_HD void opaque(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#else
+  (void)x;
+#endif
+}
+
+// fast reciprocal / division: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE sequence.
+// The parity tolerance (1e-4 relative on qvel) is four orders above its error.
+REX_HD float rcp_t(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(a);
+#else
+  return 1.0f / a;
+#endif
+}
+REX_HD double rcp_t(double a) { return 1.0 / a; }
+
 // per-lane dynamic parameters (the randomised part of the model)
 template <class T, class S>
 struct LaneParams {
@@ -151,7 +174,7 @@ template <class T, class S>
 REX_HD void ldl_factor(T (&H)[S::NV][S::NV]) {
   static_rfor<1, S::NV>([&](auto KK) {
     constexpr int k = KK;
-    T inv = T(1) / H[k][k];
+    T inv = rcp_t(H[k][k]);
     static_rfor<0, k>([&](auto II) {   // ancestors of k, deepest first
       constexpr int i = II;
       if constexpr (dof_coupled<S>(k, i)) {   // i < k and coupled  <=>  i is an ancestor dof of k
@@ -171,7 +194,7 @@ REX_HD void ldl_solve(const T (&H)[S::NV][S::NV], T (&b)[S::NV]) {
     constexpr int k = KK;
     static_for<0, k>([&](auto II) { constexpr int i = II; if constexpr (dof_coupled<S>(k, i)) b[i] -= H[k][i] * b[k]; });
   });
-  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; b[k] = b[k] / H[k][k]; });
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; b[k] = b[k] * rcp_t(H[k][k]); });
   static_for<1, S::NV>([&](auto KK) {
     constexpr int k = KK;
     static_for<0, k>([&](auto II) { constexpr int i = II; if constexpr (dof_coupled<S>(k, i)) b[k] -= H[k][i] * b[i]; });
@@ -181,35 +204,12 @@ REX_HD void ldl_solve(const T (&H)[S::NV][S::NV], T (&b)[S::NV]) {
 // [3P getimpedance] sigmoid impedance, power = 2, midpoint = 0.5 (every solimp in the four XMLs)
 template <class T>
 REX_HD T impedance(T dmin, T dmax, T width, T x_abs) {
-  T x = x_abs / width;
+  T x = x_abs * rcp_t(width);
   T y = x < T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
   T imp = dmin + y * (dmax - dmin);
   imp = x >= T(1) ? dmax : imp;
   return (dmin == dmax) ? dmin : imp;
 }
-
-// Optimisation barrier: tells the compiler the value may have changed.  Used at the top of the
-// solver loops so that LLVM's loop-invariant code motion does not hoist every lever arm and
-// Jacobian entry of every contact slot out of the loops (it does, speculatively, and the ~200
-// hoisted values then spill to scratch memory: 590 MB of HBM writes per launch were measured).
-template <class T> REX_HD void opaque(T& x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(x));
-#else
-  (void)x;
-#endif
-}
-
-// fast reciprocal / division: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE sequence.
-// The parity tolerance (1e-4 relative on qvel) is four orders above its error.
-REX_HD float rcp_t(float a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_rcpf(a);
-#else
-  return 1.0f / a;
-#endif
-}
-REX_HD double rcp_t(double a) { return 1.0 / a; }
 
 // Constraint data of one configuration.  J rows are never stored: they are rebuilt from the
 // contact point and the joint anchors whenever needed.  Slot k = 2*geom + end.
@@ -627,7 +627,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     for (int ls = 0; ls < 16; ++ls) {   // phi' is piecewise linear and increasing: safeguarded Newton
       if (!REX_WAVE_ANY(!ls_done)) break;
       if (d1 < T(0)) lo = a; else hi = a;
-      T an_ = a - d1 / d2;
+      T an_ = a - d1 * rcp_t(d2);
       if (hi >= T(0) && (an_ <= lo || an_ >= hi)) an_ = T(0.5) * (lo + hi);
       an_ = max_t(an_, lo);
       T prev = a;

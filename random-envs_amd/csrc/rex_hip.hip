@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(64) cartpole_step_kernel(DevState s, StepFlags
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            unsigned char* __restrict__ done_out, unsigned char* __restrict__ trunc_out,
                                                            float* __restrict__ term_obs) {
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
   float x = s.qpos[i], th = s.qpos[B + i], xd = s.qvel[i], thd = s.qvel[B + i];
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64) cartpole_step_kernel(DevState s, StepFlags
 __global__ void __launch_bounds__(64) cartpole_reset_kernel(DevState s, DRParams dr, int resample, int reset_state,
                                                             const unsigned char* __restrict__ mask, int mask_bit,
                                                             float* __restrict__ obs) {
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   const long long B = s.B;
@@ -192,13 +192,13 @@ __global__ void __launch_bounds__(64) cartpole_reset_kernel(DevState s, DRParams
 template <class S> constexpr int geom_floats() { return sizeof(PlanarGeom<float, S>) / sizeof(float); }
 
 template <class S>
-__device__ __forceinline__ void load_geom(const DevState& s, long long i, const PlanarGeom<float, S>& uniform,
+__device__ __forceinline__ void load_geom(const DevState& s, unsigned i, const PlanarGeom<float, S>& uniform,
                                           PlanarGeom<float, S>& G) {
   if constexpr (S::KIND == 3) {   // walker2d: geometry is a function of the xi lengths
     float* dst = reinterpret_cast<float*>(&G);
     constexpr int N = geom_floats<S>();
 #pragma unroll
-    for (int k = 0; k < N; k++) dst[k] = s.geom[(long long)k * s.B + i];
+    for (int k = 0; k < N; k++) dst[k] = (s.geom + (size_t)k * s.B)[i];
   } else {
     G = uniform;
   }
@@ -208,13 +208,13 @@ __device__ __forceinline__ void load_geom(const DevState& s, long long i, const 
 // random_walker2d.py:133-142) + optional N(0, noise_var)
 template <class S>
 __device__ __forceinline__ void write_obs(const float (&q)[S::NV], const float (&v)[S::NV], float* __restrict__ obs,
-                                          long long B, long long i, bool noisy, float noise_std,
+                                          long long B, unsigned i, bool noisy, float noise_std,
                                           rocrand_state_philox4x32_10* st) {
   static_for<0, S::NOBS>([&](auto KK) {
     constexpr int k = KK;
     float o = k < S::NV - 1 ? q[k + 1] : v[k - (S::NV - 1)];
     if (noisy) o += noise_std * rocrand_normal(st);
-    obs[(long long)k * B + i] = o;
+    (obs + (size_t)k * B)[i] = o;
   });
 }
 
@@ -224,13 +224,13 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          unsigned char* __restrict__ done_out,
                                                          unsigned char* __restrict__ trunc_out, float* __restrict__ term_obs) {
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
   float q[S::NV], v[S::NV], ctrl[S::NU], xi[S::NXI];
-  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = s.qpos[(long long)k * B + i]; v[k] = s.qvel[(long long)k * B + i]; });
-  static_for<0, S::NU>([&](auto KK) { constexpr int k = KK; ctrl[k] = action[(long long)k * B + i]; });
-  static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; xi[k] = s.xi[(long long)k * B + i]; });
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = (s.qpos + (size_t)k * B)[i]; v[k] = (s.qvel + (size_t)k * B)[i]; });
+  static_for<0, S::NU>([&](auto KK) { constexpr int k = KK; ctrl[k] = (action + (size_t)k * B)[i]; });
+  static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; xi[k] = (s.xi + (size_t)k * B)[i]; });
   PlanarGeom<float, S> G; load_geom<S>(s, i, ugeom, G);
   LaneParams<float, S> P; lane_params(S{}, xi, P);
   // the dynamics are invariant to the root x translation: integrate the step from x = 0 so the
@@ -266,13 +266,13 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   int t = s.t[i] + 1; s.t[i] = t;
   bool trunc = fl.time_limit && t >= fl.max_steps && !dn;     // gym TimeLimit
   bool d = dn || trunc;
-  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; s.qpos[(long long)k * B + i] = q[k]; s.qvel[(long long)k * B + i] = v[k]; });
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = q[k]; (s.qvel + (size_t)k * B)[i] = v[k]; });
   s.done[i] = d ? 2 : 0;
   rocrand_state_philox4x32_10 st;
   if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
                              (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
   write_obs<S>(q, v, obs, B, i, fl.noisy != 0, fl.noise_std, &st);
-  if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; term_obs[(long long)k * B + i] = obs[(long long)k * B + i]; });
+  if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; (term_obs + (size_t)k * B)[i] = (obs + (size_t)k * B)[i]; });
   reward[i] = r; done_out[i] = d ? 1 : 0;
   if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
 }
@@ -283,7 +283,7 @@ template <class S>
 __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
                                                           const unsigned char* __restrict__ mask, int mask_bit,
                                                           float* __restrict__ obs) {
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   const long long B = s.B;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
       else v[k] = c * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
     });
     if constexpr (S::KIND != 2) q[1] += 1.25f;                             // init_qpos[1] = 1.25 (ref, hopper.xml:30)
-    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; s.qpos[(long long)k * B + i] = q[k]; s.qvel[(long long)k * B + i] = v[k]; });
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = q[k]; (s.qvel + (size_t)k * B)[i] = v[k]; });
     s.t[i] = 0; s.done[i] = 0;
     if (obs) {
       rocrand_state_philox4x32_10 st2;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
     rocrand_state_philox4x32_10 st3;   // separate stream region so the xi draw does not depend on reset_state
     rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, &st3);
     float xi[S::NXI]; sample_task<S::NXI>(dr, &st3, xi, s.counters);
-    static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; s.xi[(long long)k * B + i] = xi[k]; });
+    static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; (s.xi + (size_t)k * B)[i] = xi[k]; });
   }
 }
 
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
 // (replaces build_model() inside RandomWalker2dEnv.set_task, random_walker2d.py:106-113).
 __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit) {
   using S = Walker2dSpec;
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   double size[4];
@@ -328,19 +328,19 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
   derive_model<double, S>(size, G, nominal, sp);
   const double* src = reinterpret_cast<const double*>(&G);
   constexpr int N = geom_floats<S>();
-  for (int k = 0; k < N; k++) s.geom[(long long)k * s.B + i] = (float)src[k];
+  for (int k = 0; k < N; k++) (s.geom + (size_t)k * s.B)[i] = (float)src[k];
 }
 
 template <class S>
 __global__ void __launch_bounds__(64) planar_obs_kernel(DevState s, float* __restrict__ obs) {
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   float q[S::NV], v[S::NV];
-  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = s.qpos[(long long)k * s.B + i]; v[k] = s.qvel[(long long)k * s.B + i]; });
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = (s.qpos + (size_t)k * s.B)[i]; v[k] = (s.qvel + (size_t)k * s.B)[i]; });
   write_obs<S>(q, v, obs, s.B, i, false, 0.0f, nullptr);
 }
 __global__ void __launch_bounds__(64) cartpole_obs_kernel(DevState s, float* __restrict__ obs) {
-  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
   obs[i] = s.qpos[i]; obs[B + i] = s.qvel[i]; obs[2 * B + i] = s.qpos[B + i]; obs[3 * B + i] = s.qvel[B + i];
