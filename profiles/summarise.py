@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise a profiles/collect.sh run: kernel stats CSV + per-launch PMC means -> profiles/<tag>_*.
+Usage: python profiles/summarise.py <tag>"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+ks = glob.glob(os.path.join(P, "trace", "*", "*_kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
+out = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for f in glob.glob(os.path.join(P, name, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "planar" in k or "cartpole" in k:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                out.setdefault(k, {}).setdefault("_regs", {"VGPR": r.get("VGPR_Count"), "AGPR": r.get("Accum_VGPR_Count"),
+                                                           "SGPR": r.get("SGPR_Count"), "scratch": r.get("Scratch_Size"),
+                                                           "LDS": r.get("LDS_Block_Size")})
+        for k, v in agg.items():
+            for c, vals in v.items():
+                out.setdefault(k, {})[c] = {"n": len(vals), "mean_per_launch": sum(vals) / len(vals)}
+# HBM traffic per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads.
+for k, v in out.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        f = v["FETCH_SIZE"]["mean_per_launch"] * 1024; w = v["WRITE_SIZE"]["mean_per_launch"] * 1024
+        v["hbm_bytes_per_launch"] = {"fetch_raw": f, "fetch_x2_gfx950": 2 * f, "write": w, "total_corrected": 2 * f + w}
+json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
+step = [k for k in out if "planar_step_kernel" in k]
+if step and "hbm_bytes_per_launch" in out[step[0]]:
+    json.dump({"kernel": step[0], "bytes_per_launch": out[step[0]]["hbm_bytes_per_launch"]["total_corrected"],
+               "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag},
+              open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"))
+print(json.dumps(out, indent=1)[:3000])
