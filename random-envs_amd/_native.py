@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librex_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("REX_LIB", "librex_hip.so"))   # REX_LIB: A/B builds while tuning
 
 # every symbol include/rex.h declares (tests check the built library exports all of them)
 SYMBOLS = [

@@ -459,6 +459,18 @@ REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const
 }
 
 struct SolveStats { int iters; bool capped; };
+#if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; };
+inline GlobalStats& gstats() { static GlobalStats g{}; return g; }
+#define REX_COUNT(field, n) (gstats().field += (n))
+#elif defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
+// diagnostic build only: wave-level event counts (lane 0 of each wave adds)
+extern __device__ unsigned long long g_kstats[8];
+enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4, KS_nocon = 5, KS_slots_active = 6 };
+#define REX_COUNT(field, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_kstats[KS_##field], (unsigned long long)(n)); } while (0)
+#else
+#define REX_COUNT(field, n) ((void)0)
+#endif
 
 // Primal Newton solve of   min_a 0.5 (a-a0)^T M (a-a0) + sum_rows 0.5 D min(0, J a - aref)^2
 // ([3P] engine_solver, Newton, pyramidal cones): exact Hessian M + J^T D_active J with the tree
@@ -486,6 +498,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     if (!REX_WAVE_ANY(!lane_done)) break;
     T cpx[NC], cpz[NC];   // per-iteration opaque copies of the contact points (see opaque())
     static_for<0, NC>([&](auto KK) { constexpr int k = KK; cpx[k] = C.px[k]; cpz[k] = C.pz[k]; opaque(cpx[k]); opaque(cpz[k]); });
+    REX_COUNT(pass1, 1);
     // ---- pass 1: gradient and active edges --------------------------------------------------
     T g[S::NV], Ma[S::NV];
     sym_matvec<T, S>(M, qacc, Ma);
@@ -541,6 +554,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     p_lim = lim_on; p_e1 = e1; p_e2 = e2; p_e3 = e3; p_self = self_on;
     lane_done = lane_done || same_set || !(gn > tol2 * fref);   // NaN counts as done
     if (!REX_WAVE_ANY(!lane_done)) break;
+    REX_COUNT(pass2, 1);
     // ---- pass 2: Hessian of the current active set, Newton direction ------------------------
     T H[S::NV][S::NV];
     static_for<0, S::NV>([&](auto II) { constexpr int i = II;
@@ -582,13 +596,16 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     sym_matvec<T, S>(M, sr, Ms);
     T q1 = T(0), q2 = T(0), d0 = T(0);
     static_for<0, S::NV>([&](auto II) { q1 += sr[II] * (Ma[II] - qfrc_smooth[II]); q2 += sr[II] * Ms[II]; d0 += sr[II] * g[II]; });
+    unsigned m_lim, m_e1, m_e2, m_e3, m_self;   // rows active at the last evaluated alpha
     auto deriv = [&](T a, T& d1, T& d2) {
-      static_for<0, NC>([&](auto KK) { constexpr int k = KK; opaque(cpx[k]); opaque(cpz[k]); });
+      REX_COUNT(ls_evals, 1);
+      m_lim = m_e1 = m_e2 = m_e3 = m_self = 0u;
       d1 = q1 + a * q2; d2 = q2;
       static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
         if constexpr (S::limited[j]) {
           T lr = C.lsig[j] * qacc[j + 2] - C.laref[j], lv = C.lsig[j] * sr[j + 2];
           T x = lr + a * lv; bool on = ((C.lim_mask >> j) & 1u) && x < T(0);
+          if (on) m_lim |= 1u << j;
           T dd = on ? C.lD[j] : T(0); d1 += dd * x * lv; d2 += dd * lv * lv; } });
       static_for<0, S::NG>([&](auto GG) {
         constexpr int gg = GG; constexpr int b = S::geom_body[gg];
@@ -601,7 +618,9 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
             T r0 = jn + mu * jt - (C.an[k] + C.at[k]), r1 = jn - mu * jt - (C.an[k] - C.at[k]), r2 = jn - C.an[k];
             T v0 = vn + mu * vt, v1 = vn - mu * vt, v2 = vn;
             T x0 = r0 + a * v0, x1 = r1 + a * v1, x2 = r2 + a * v2;
-            T w0 = (act && x0 < T(0)) ? C.D[k] : T(0), w1 = (act && x1 < T(0)) ? C.D[k] : T(0), w2 = (act && x2 < T(0)) ? T(2) * C.D[k] : T(0);
+            const bool o0 = act && x0 < T(0), o1 = act && x1 < T(0), o2 = act && x2 < T(0);
+            if (o0) m_e1 |= 1u << k; if (o1) m_e2 |= 1u << k; if (o2) m_e3 |= 1u << k;
+            T w0 = o0 ? C.D[k] : T(0), w1 = o1 ? C.D[k] : T(0), w2 = o2 ? T(2) * C.D[k] : T(0);
             d1 += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2;
             d2 += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2;
           }
@@ -614,7 +633,9 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           T ta, na, tb, nb, ua, ma_, ub, mb_;
           jdot2<T, S, ba>(K, R.px[p], R.pz[p], qacc, sr, ta, na, ua, ma_); jdot2<T, S, bb>(K, R.px[p], R.pz[p], qacc, sr, tb, nb, ub, mb_);
           T r = R.nx[p] * (tb - ta) + R.nz[p] * (nb - na) - R.aref[p], vv = R.nx[p] * (ub - ua) + R.nz[p] * (mb_ - ma_);
-          T x = r + a * vv; T dd = (act && x < T(0)) ? R.D[p] : T(0);
+          T x = r + a * vv; const bool on = act && x < T(0);
+          if (on) m_self |= 1u << p;
+          T dd = on ? R.D[p] : T(0);
           d1 += dd * x * vv; d2 += dd * vv * vv;
         }
       });
@@ -635,25 +656,40 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       deriv(a, d1, d2);
       ls_done = ls_done || abs_t(d1) <= d1ref || a == prev;
     }
+    // full Newton step that stays in the region its Hessian was built for: exact minimiser, no
+    // verification pass needed (same argument as `same_set` above)
+    const bool exact_step = a == T(1) && m_lim == lim_on && m_e1 == e1 && m_e2 == e2 && m_e3 == e3 && m_self == self_on;
     a = lane_done ? T(0) : a;
     T amax = T(0), smax = T(0);
     static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; amax = max_t(amax, abs_t(qacc[II])); smax = max_t(smax, abs_t(a * sr[II])); });
 #if defined(REX_DEBUG_SOLVER) && !defined(__HIP_DEVICE_COMPILE__)
     if (it >= 12) printf("     alpha %.6g smax %.3e amax %.3e d1 %.3e d0 %.3e\n", double(a), double(smax), double(amax), double(d1), double(d0));
 #endif
-    lane_done = lane_done || smax <= stag * (T(1) + amax);   // stagnation at rounding level
+    lane_done = lane_done || exact_step || smax <= stag * (T(1) + amax);   // stagnation at rounding level
     st.iters = it + 1;
     if (it == MAXIT - 1) st.capped = REX_WAVE_ANY(!lane_done);
   }
   return st;
 }
 
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+// diagnostic build only: per-phase cycle stamps (s_memtime), summed per wave into g_ktime[]
+extern __device__ unsigned long long g_ktime[8];
+#define REX_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define REX_TACC(slot, t0, t1) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[slot], (t1) - (t0)); } while (0)
+#else
+#define REX_STAMP(var) ((void)0)
+#define REX_TACC(slot, t0, t1) ((void)0)
+#endif
+
 // one forward-dynamics evaluation: qacc(q, v, ctrl)  ([3P] mj_forward)
 template <class T, class S>
 REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
                           const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV]) {
+  REX_STAMP(t_0);
   Kin<T, S> K;
   kinematics<T, S>(q, G, K);
+  REX_STAMP(t_1);
   T f[S::NV], a0[S::NV];
   {
     T bias[S::NV];
@@ -665,6 +701,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
       f[j + 2] = -G.damping[j] * v[j + 2] - G.stiffness[j] * q[j + 2] - bias[j + 2] + T(S::gear[j - 1]) * c;
     });
   }
+  REX_STAMP(t_2);
   {
     T L[S::NV][S::NV];
     static_for<0, S::NV>([&](auto II) { constexpr int i = II; a0[i] = f[i];
@@ -672,9 +709,17 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
     ldl_factor<T, S>(L);
     ldl_solve<T, S>(L, a0);
   }
+  REX_STAMP(t_3);
   Constraints<T, S> C;
   make_constraints<T, S>(q, v, G, P, sp, K, C);
+  REX_STAMP(t_4);
   SolveStats st{0, false};
+#if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
+  { unsigned um = 0; for (int k = 0; k < 2 * S::NG; k++) if (REX_WAVE_ANY((C.con_mask >> k) & 1u)) um |= 1u << k;
+    REX_COUNT(solves, 1); if (!REX_WAVE_ANY(C.any)) REX_COUNT(nocon, 1); REX_COUNT(slots_active, __popc(um)); }
+#else
+  REX_COUNT(solves, 1); if (!C.any) REX_COUNT(nocon, 1); REX_COUNT(slots_active, __builtin_popcount(C.con_mask));
+#endif
   bool self_path = false;
   if constexpr (S::NSELF > 0) self_path = REX_WAVE_ANY(C.self_possible);
   if (self_path) {   // rare: a capsule-capsule self contact may exist somewhere in this wave
@@ -687,6 +732,11 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   } else {
     static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
   }
+  REX_STAMP(t_5);
+  REX_TACC(0, t_0, t_1); REX_TACC(1, t_1, t_2); REX_TACC(2, t_2, t_3); REX_TACC(3, t_3, t_4); REX_TACC(4, t_4, t_5);
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[7], 1ull);
+#endif
   return st;
 }
 

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -26,6 +27,19 @@
 #include "planar_model.hpp"
 
 using namespace rex;
+
+#if defined(REX_KTIME)
+namespace rex { __device__ unsigned long long g_ktime[8]; }
+extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build only (not in rex.h)
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_ktime), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_ktime), z, sizeof z); return 0; }
+#endif
+#if defined(REX_KSTATS)
+namespace rex { __device__ unsigned long long g_kstats[8]; }
+extern "C" int rex_debug_kstats(unsigned long long* out) {   // diagnostic build only (not in rex.h)
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_kstats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_kstats), z, sizeof z); return 0; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -131,7 +145,7 @@ __global__ void __launch_bounds__(64) cartpole_step_kernel(DevState s, StepFlags
                                                            float* __restrict__ obs, float* __restrict__ reward,
                                                            unsigned char* __restrict__ done_out, unsigned char* __restrict__ trunc_out,
                                                            float* __restrict__ term_obs) {
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
   float x = s.qpos[i], th = s.qpos[B + i], xd = s.qvel[i], thd = s.qvel[B + i];
@@ -164,7 +178,7 @@ __global__ void __launch_bounds__(64) cartpole_step_kernel(DevState s, StepFlags
 __global__ void __launch_bounds__(64) cartpole_reset_kernel(DevState s, DRParams dr, int resample, int reset_state,
                                                             const unsigned char* __restrict__ mask, int mask_bit,
                                                             float* __restrict__ obs) {
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   const long long B = s.B;
@@ -224,7 +238,7 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          unsigned char* __restrict__ done_out,
                                                          unsigned char* __restrict__ trunc_out, float* __restrict__ term_obs) {
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
   float q[S::NV], v[S::NV], ctrl[S::NU], xi[S::NXI];
@@ -235,11 +249,17 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   LaneParams<float, S> P; lane_params(S{}, xi, P);
   // the dynamics are invariant to the root x translation: integrate the step from x = 0 so the
   // forward-progress reward (posafter - posbefore)/dt keeps full fp32 resolution far from the origin
+#if defined(REX_KTIME)
+  unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
   const float x_before = q[0];
   q[0] = 0.0f;
   bool capped = false;
 #pragma unroll 1
   for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S>(q, v, ctrl, G, P, sp);   // do_simulation, jinja_mujoco_env.py:170-173
+#if defined(REX_KTIME)
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[5], __builtin_amdgcn_s_memtime() - tk0);
+#endif
   const float dx = q[0];
   q[0] = x_before + dx;
   // reward / done
@@ -283,7 +303,7 @@ template <class S>
 __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
                                                           const unsigned char* __restrict__ mask, int mask_bit,
                                                           float* __restrict__ obs) {
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   const long long B = s.B;
@@ -319,7 +339,7 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
 // (replaces build_model() inside RandomWalker2dEnv.set_task, random_walker2d.py:106-113).
 __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit) {
   using S = Walker2dSpec;
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   double size[4];
@@ -333,14 +353,14 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
 
 template <class S>
 __global__ void __launch_bounds__(64) planar_obs_kernel(DevState s, float* __restrict__ obs) {
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   float q[S::NV], v[S::NV];
   static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = (s.qpos + (size_t)k * s.B)[i]; v[k] = (s.qvel + (size_t)k * s.B)[i]; });
   write_obs<S>(q, v, obs, s.B, i, false, 0.0f, nullptr);
 }
 __global__ void __launch_bounds__(64) cartpole_obs_kernel(DevState s, float* __restrict__ obs) {
-  const unsigned i = blockIdx.x * 64u + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
   obs[i] = s.qpos[i]; obs[B + i] = s.qvel[i]; obs[2 * B + i] = s.qpos[B + i]; obs[3 * B + i] = s.qvel[B + i];
@@ -420,10 +440,19 @@ static void host_derive(rex_env* h, PlanarGeom<float, S>& out) {
   for (int b = 0; b < S::NB; b++) h->nominal_xi[b] = (float)nominal[b];
 }
 
-static unsigned grid_for(long long B) { return (unsigned)((B + 63) / 64); }
+// Lanes per workgroup (= per wavefront).  The step kernels are latency-bound (one wave per SIMD,
+// ~9 cycles per dependent VALU instruction against a 2-cycle issue), so what matters is the number
+// of resident WAVES, not the lanes each one fills: below 64 Ki envs a full-width launch leaves
+// SIMDs idle (32768 envs = 512 waves on 1024 SIMDs), half-filled waves put one on every SIMD.
+static int lanes_for(long long B) {
+  const char* e = getenv("REX_LANES");
+  if (e && atoi(e) > 0) return atoi(e);
+  return B >= 65536 ? 64 : 32;
+}
+static unsigned grid_for(long long B) { int l = lanes_for(B); return (unsigned)((B + l - 1) / l); }
 
 static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st) {
-  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h->B)), dim3(64), 0, st, h->dev, mask, bit);
+  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, st, h->dev, mask, bit);
   HIP_TRY(hipGetLastError());
   return REX_OK;
 }
@@ -476,6 +505,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
   }
   h->flags.noise_std = sqrtf(noise_var);
+  if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * dims.task_dim, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, dims.task_dim, (long long)B);
@@ -543,7 +573,7 @@ extern "C" int rex_set_autoreset(rex_t* h, int autoreset, int time_limit) {
 extern "C" int rex_seed(rex_t* h, uint64_t seed) { if (!h) return set_err(REX_ERR_ARG, "null handle"); h->seed = seed; h->dev.seed = seed; return REX_OK; }
 
 static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, int reset_state, float* obs, hipStream_t st) {
-  const dim3 g(grid_for(h->B)), b(64);
+  const dim3 g(grid_for(h->B)), b(lanes_for(h->B));
   if (resample && h->dr.type == REX_DR_NONE) return set_err(REX_ERR_STATE,
       "sampling value of random env needs to be set before using sample_task() or set_random_task()");   // random_env.py:201
   switch (h->kind) {
@@ -575,7 +605,7 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   if (!h) return set_err(REX_ERR_ARG, "null handle");
   if (!action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_step: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g(grid_for(h->B)), b(64);
+  const dim3 g(grid_for(h->B)), b(lanes_for(h->B));
   if (h->timing) {
     if (h->ev_n >= h->ev0.size()) {
       hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
@@ -630,7 +660,7 @@ extern "C" int rex_set_task(rex_t* h, const float* xi, void* stream) {
 }
 extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
   if (!h || !obs_out) return set_err(REX_ERR_ARG, "rex_get_obs: null argument");
-  const dim3 g(grid_for(h->B)), b(64); hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid_for(h->B)), b(lanes_for(h->B)); hipStream_t st = (hipStream_t)stream;
   switch (h->kind) {
     case REX_CARTPOLE: hipLaunchKernelGGL(cartpole_obs_kernel, g, b, 0, st, h->dev, obs_out); break;
     case REX_HOPPER: hipLaunchKernelGGL(planar_obs_kernel<HopperSpec>, g, b, 0, st, h->dev, obs_out); break;
