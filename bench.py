@@ -35,7 +35,7 @@ KERNEL_NAME = {"RandomHopper-v0": "planar_step_kernel<HopperSpec>", "RandomWalke
                "RandomHalfCheetahNoisy-v0": "planar_step_kernel<HalfCheetahSpec>", "RandomCartPole-v0": "cartpole_step_kernel"}
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
-NOMINAL = [3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 5.0893800988154645]
+NOMINAL = [3.5342917352885186, 3.9269908169872427, 2.7143360527015816, 5.0893800988154645]
 
 
 def cpu_baseline(batch, steps, seed=0, min_seconds=12.0):

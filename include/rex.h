@@ -72,7 +72,9 @@ typedef struct rex_dims {
   float act_low, act_high; /* actuator_ctrlrange, jinja_mujoco_env.py:99-103 */
 } rex_dims;
 
-int rex_get_dims(int env_kind, rex_dims* out);
+/* variant: 0 = regular id, 1 = the "Unmodeled" id of the same chain (e.g. random_hopper_unmodeled.py:16-43): a
+ * prefix of xi is frozen at 0.8x nominal and leaves the task vector, so task_dim shrinks (3 / 5 / 9). */
+int rex_get_dims(int env_kind, int variant, rex_dims* out);
 
 /* Replaces MujocoEnv.__init__ / build_model (jinja_mujoco_env.py:43-97): load_model_from_xml +
  * MjSim for `batch` environments at once.  `env_offset` is the global index of this handle's

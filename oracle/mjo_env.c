@@ -21,13 +21,23 @@ int mjo_env_init(mjoEnv* e, int kind, int variant) {
   switch (kind) {
     case MJO_ENV_HOPPER:      /* random_hopper.py:30 frame_skip 4; obs 11; xi = 4 masses */
       memcpy(e->size, HOPPER_SIZE, sizeof HOPPER_SIZE); mjo_build_hopper(&e->model, e->size);
-      e->frame_skip = 4; e->obs_dim = 11; e->task_dim = 4; e->act_dim = 3; break;
+      e->frame_skip = 4; e->obs_dim = 11; e->task_dim = variant ? 3 : 4; e->act_dim = 3;
+      /* Unmodeled: torso mass frozen at 0.8x nominal (random_hopper_unmodeled.py:24-26) */
+      if (variant) e->model.body_mass[1] *= 0.8;
+      break;
     case MJO_ENV_WALKER2D:    /* random_walker2d.py:32; xi = 7 masses + 4 lengths + 2 frictions */
-      memcpy(e->size, WALKER_SIZE, sizeof WALKER_SIZE); mjo_build_walker2d(&e->model, e->size);
-      e->frame_skip = 4; e->obs_dim = 17; e->task_dim = 13; e->act_dim = 6; break;
+      memcpy(e->size, WALKER_SIZE, sizeof WALKER_SIZE);
+      if (variant) e->size[0] *= 0.8;   /* torso length frozen at 0.8x (random_walker2d_unmodeled.py:25-27) */
+      mjo_build_walker2d(&e->model, e->size);
+      e->frame_skip = 4; e->obs_dim = 17; e->task_dim = variant ? 9 : 13; e->act_dim = 6;
+      /* masses 1..3 at 0.8x until the first set_task rebuilds the model (:33-36) */
+      if (variant) for (int b = 1; b <= 3; b++) e->model.body_mass[b] *= 0.8;
+      break;
     case MJO_ENV_HALFCHEETAH: /* random_half_cheetah.py:33; xi = 7 masses + 1 friction */
       mjo_build_halfcheetah(&e->model, NULL);
-      e->frame_skip = 5; e->obs_dim = 17; e->task_dim = 8; e->act_dim = 6; break;
+      e->frame_skip = 5; e->obs_dim = 17; e->task_dim = variant ? 5 : 8; e->act_dim = 6;
+      if (variant) for (int b = 1; b <= 3; b++) e->model.body_mass[b] *= 0.8;   /* random_half_cheetah_unmodeled.py:28-31 */
+      break;
     default: return -1;
   }
   mjo_reset_data(&e->model, &e->data);
@@ -40,6 +50,21 @@ void mjo_set_tolerance(double tol) { g_tolerance = tol; }
 
 void mjo_env_get_task(const mjoEnv* e, double* xi) {
   const mjoModel* m = &e->model;
+  if (e->variant) {   /* Unmodeled ids: the frozen prefix is not part of xi */
+    switch (e->kind) {
+      case MJO_ENV_HOPPER:      /* random_hopper_unmodeled.py:71-73 */
+        for (int i = 0; i < 3; i++) xi[i] = m->body_mass[2 + i];
+        break;
+      case MJO_ENV_HALFCHEETAH: /* random_half_cheetah_unmodeled.py:82-86 */
+        for (int i = 0; i < 4; i++) xi[i] = m->body_mass[4 + i];
+        xi[4] = m->pair_friction[0][0]; break;
+      case MJO_ENV_WALKER2D:    /* random_walker2d_unmodeled.py:104-107 */
+        for (int i = 0; i < 4; i++) xi[i] = m->body_mass[4 + i];
+        for (int i = 0; i < 3; i++) xi[4 + i] = e->size[1 + i];
+        xi[7] = m->pair_friction[0][0]; xi[8] = m->pair_friction[1][0]; break;
+    }
+    return;
+  }
   switch (e->kind) {
     case MJO_ENV_HOPPER:      /* random_hopper.py:75-77 */
       for (int i = 0; i < 4; i++) xi[i] = m->body_mass[1 + i];
@@ -56,6 +81,25 @@ void mjo_env_get_task(const mjoEnv* e, double* xi) {
 
 void mjo_env_set_task(mjoEnv* e, const double* xi) {
   mjoModel* m = &e->model;
+  if (e->variant) {
+    switch (e->kind) {
+      case MJO_ENV_HOPPER:      /* random_hopper_unmodeled.py:75-76 */
+        for (int i = 0; i < 3; i++) m->body_mass[2 + i] = xi[i];
+        break;
+      case MJO_ENV_HALFCHEETAH: /* random_half_cheetah_unmodeled.py:94-95 */
+        for (int i = 0; i < 4; i++) m->body_mass[4 + i] = xi[i];
+        for (int p = 0; p < 2; p++) { m->pair_friction[p][0] = xi[4]; m->pair_friction[p][1] = xi[4]; } break;
+      case MJO_ENV_WALKER2D:    /* random_walker2d_unmodeled.py:109-116: the rebuild drops the 0.8x mass scaling */
+        for (int i = 0; i < 3; i++) e->size[1 + i] = xi[4 + i];
+        mjo_build_walker2d(m, e->size);
+        for (int i = 0; i < 4; i++) m->body_mass[4 + i] = xi[i];
+        m->pair_friction[0][0] = xi[7]; m->pair_friction[0][1] = xi[7];
+        m->pair_friction[1][0] = xi[8]; m->pair_friction[1][1] = xi[8];
+        mjo_reset_data(m, &e->data);
+        break;
+    }
+    return;
+  }
   switch (e->kind) {
     case MJO_ENV_HOPPER:      /* random_hopper.py:79-80: body_mass[1:] = task (inertia, invweight0 untouched) */
       for (int i = 0; i < 4; i++) m->body_mass[1 + i] = xi[i];
@@ -143,7 +187,8 @@ static void* batch_worker(void* arg) {
   for (int i = j->lo; i < j->hi; i++) {
     for (int k = 0; k < nx; k++) xi[k] = j->xi[(size_t)k * n + i];
     /* Walker2d set_task recompiles the model: skip when xi is unchanged */
-    if (!have_xi || memcmp(xi, last_xi, sizeof(double) * nx)) { mjo_env_set_task(e, xi); memcpy(last_xi, xi, sizeof(double) * nx); have_xi = 1; }
+    /* a NaN xi keeps the freshly constructed model (used to test the Unmodeled ids before any set_task) */
+    if (xi[0] == xi[0] && (!have_xi || memcmp(xi, last_xi, sizeof(double) * nx))) { mjo_env_set_task(e, xi); memcpy(last_xi, xi, sizeof(double) * nx); have_xi = 1; }
     for (int k = 0; k < nq; k++) q[k] = j->qpos[(size_t)k * n + i];
     for (int k = 0; k < nv; k++) v[k] = j->qvel[(size_t)k * n + i];
     mjo_env_set_state(e, q, v);

@@ -48,7 +48,7 @@ def lib():
         raise RexError("cannot load %s: %s" % (LIB_PATH, e))
     vp, i32, i64, u64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
     fp = ctypes.POINTER(ctypes.c_float)
-    L.rex_get_dims.argtypes = [i32, ctypes.POINTER(RexDims)]
+    L.rex_get_dims.argtypes = [i32, i32, ctypes.POINTER(RexDims)]
     L.rex_create.argtypes = [i32, i32, i64, i32, u64, i64, ctypes.POINTER(vp)]
     L.rex_destroy.argtypes = [vp]
     L.rex_set_dr.argtypes = [vp, i32, fp, i32, fp]

@@ -67,6 +67,8 @@ struct DRParams {
   float b[MAX_XI];          // uniform: hi   | truncnorm/gaussian: std
   float lower[MAX_XI];      // get_task_lower_bound(i)
   float lo[MAX_XI], hi[MAX_XI];   // fullgaussian: search bounds for denormalisation
+  int map[MAX_XI];          // task index -> row of the kernels' full xi block (identity for the regular ids;
+                            // the Unmodeled ids randomise a suffix only)
   float chol[MAX_XI * MAX_XI];    // fullgaussian: lower Cholesky factor of cov, row-major
 };
 
@@ -81,16 +83,14 @@ __device__ __forceinline__ float truncnorm2(float u) {
   return fminf(fmaxf(x, -2.0f), 2.0f);
 }
 
-// RandomEnv.sample_task (random_env.py:148-203), one lane = one env.
-template <int NXI>
-__device__ void sample_task(const DRParams& dr, rocrand_state_philox4x32_10* st, float (&xi)[NXI],
-                            unsigned long long* counters) {
+// RandomEnv.sample_task (random_env.py:148-203), one lane = one env.  Cold path (reset only):
+// runtime dimension, rolled loops.
+__device__ void sample_task(const DRParams& dr, rocrand_state_philox4x32_10* st, float* xi, unsigned long long* counters) {
+  const int d = dr.dim;
   if (dr.type == REX_DR_UNIFORM) {           // :150-151  U(min, max) per dim
-#pragma unroll
-    for (int k = 0; k < NXI; k++) { float u = rocrand_uniform(st); xi[k] = dr.a[k] + (dr.b[k] - dr.a[k]) * (1.0f - u); }
+    for (int k = 0; k < d; k++) { float u = rocrand_uniform(st); xi[k] = dr.a[k] + (dr.b[k] - dr.a[k]) * (1.0f - u); }
   } else if (dr.type == REX_DR_TRUNCNORM) {  // :153-171 (intended semantics; the reference raises NameError)
-#pragma unroll
-    for (int k = 0; k < NXI; k++) {
+    for (int k = 0; k < d; k++) {
       float lb = dr.lower[k];
       float obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(st));
       // `attempts` 1,2 keep a redraw; the third redraw is overwritten by lower_bound (:162-167)
@@ -99,21 +99,17 @@ __device__ void sample_task(const DRParams& dr, rocrand_state_philox4x32_10* st,
       xi[k] = obs;
     }
   } else if (dr.type == REX_DR_GAUSSIAN) {   // :173-190: redraw while < 0.1, raise after the 3rd failure
-#pragma unroll
-    for (int k = 0; k < NXI; k++) {
+    for (int k = 0; k < d; k++) {
       float obs = dr.a[k] + dr.b[k] * rocrand_normal(st);
       for (int att = 0; att < 2 && obs < 0.1f; att++) obs = dr.a[k] + dr.b[k] * rocrand_normal(st);
       if (obs < 0.1f) { obs = 0.1f; atomicAdd(counters + 1, 1ull); }   // a device lane cannot raise: clamp + count
       xi[k] = obs;
     }
   } else if (dr.type == REX_DR_FULLGAUSSIAN) {  // :192-198: MVN in normalised [0,4]^d, clip, denormalise (:205-220)
-    float z[NXI];
-#pragma unroll
-    for (int k = 0; k < NXI; k++) z[k] = rocrand_normal(st);
-#pragma unroll
-    for (int k = 0; k < NXI; k++) {
+    float z[MAX_XI];
+    for (int k = 0; k < d; k++) z[k] = rocrand_normal(st);
+    for (int k = 0; k < d; k++) {
       float s = dr.a[k];
-#pragma unroll
       for (int j = 0; j <= k; j++) s += dr.chol[k * MAX_XI + j] * z[j];
       s = fminf(fmaxf(s, 0.0f), 4.0f);
       xi[k] = s * (dr.hi[k] - dr.lo[k]) * 0.25f + dr.lo[k];
@@ -194,9 +190,8 @@ __global__ void __launch_bounds__(64) cartpole_reset_kernel(DevState s, DRParams
     if (obs) { obs[i] = v[0]; obs[B + i] = v[1]; obs[2 * B + i] = v[2]; obs[3 * B + i] = v[3]; }
   }
   if (resample && dr.type != REX_DR_NONE) {
-    float xi[4]; sample_task<4>(dr, &st, xi, s.counters);
-#pragma unroll
-    for (int k = 0; k < 4; k++) s.xi[k * B + i] = xi[k];
+    float xi[MAX_XI]; sample_task(dr, &st, xi, s.counters);
+    for (int k = 0; k < dr.dim; k++) s.xi[(size_t)dr.map[k] * B + i] = xi[k];
   }
 }
 
@@ -330,14 +325,15 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
   if (resample && dr.type != REX_DR_NONE) {
     rocrand_state_philox4x32_10 st3;   // separate stream region so the xi draw does not depend on reset_state
     rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, &st3);
-    float xi[S::NXI]; sample_task<S::NXI>(dr, &st3, xi, s.counters);
-    static_for<0, S::NXI>([&](auto KK) { constexpr int k = KK; (s.xi + (size_t)k * B)[i] = xi[k]; });
+    float xi[MAX_XI]; sample_task(dr, &st3, xi, s.counters);
+    for (int k = 0; k < dr.dim; k++) (s.xi + (size_t)dr.map[k] * B)[i] = xi[k];
   }
 }
 
 // walker2d: re-derive the per-env model constants from the xi lengths for the masked lanes
 // (replaces build_model() inside RandomWalker2dEnv.set_task, random_walker2d.py:106-113).
-__global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit) {
+__global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit,
+                                                           int refresh_frozen_masses) {
   using S = Walker2dSpec;
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
@@ -349,6 +345,9 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
   const double* src = reinterpret_cast<const double*>(&G);
   constexpr int N = geom_floats<S>();
   for (int k = 0; k < N; k++) (s.geom + (size_t)k * s.B)[i] = (float)src[k];
+  // RandomWalker2dUnmodeled.set_task rebuilds the model and rewrites body_mass[4:] only, so the frozen
+  // masses 1..3 become the geometry-derived ones of the new lengths (random_walker2d_unmodeled.py:109-116)
+  if (refresh_frozen_masses) for (int b = 0; b < 3; b++) (s.xi + (size_t)b * s.B)[i] = (float)nominal[b];
 }
 
 template <class S>
@@ -389,7 +388,8 @@ struct rex_env {
   PlanarGeom<float, HalfCheetahSpec> g_cheetah{};
   PlanarGeom<float, Walker2dSpec> g_walker{};
   SolParams<float> sp{};
-  float nominal_xi[MAX_XI] = {0};
+  float nominal_xi[MAX_XI] = {0};   // FULL xi block of the kernels
+  int full_dim = 0;                 // rows of the full xi block (dims.task_dim = rows exposed as the task)
   float* d_scratch = nullptr;   // MAX_XI floats
   // timing
   int timing = 0;
@@ -397,26 +397,46 @@ struct rex_env {
   size_t ev_n = 0;
 };
 
-static int fill_dims(int kind, rex_dims* d) {
+static int fill_dims(int kind, int variant, rex_dims* d) {
   memset(d, 0, sizeof *d);
   d->max_episode_steps = 500;                 // every gym.envs.register call, e.g. random_hopper.py:155-166
+  int rc = -1;
   switch (kind) {
     case REX_CARTPOLE:    d->nq = 2; d->nv = 2; d->act_dim = 1; d->obs_dim = 4; d->task_dim = 4; d->frame_skip = 1;
-                          d->discrete_action = 1; d->dt = 0.02f; d->act_low = 0; d->act_high = 1; return 0;
+                          d->discrete_action = 1; d->dt = 0.02f; d->act_low = 0; d->act_high = 1; rc = 0; break;
     case REX_HOPPER:      d->nq = 6; d->nv = 6; d->act_dim = 3; d->obs_dim = 11; d->task_dim = 4; d->frame_skip = 4;
-                          d->dt = 0.008f; d->act_low = -1; d->act_high = 1; return 0;
+                          d->dt = 0.008f; d->act_low = -1; d->act_high = 1; rc = 0; break;
     case REX_HALFCHEETAH: d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 8; d->frame_skip = 5;
-                          d->dt = 0.05f; d->act_low = -1; d->act_high = 1; return 0;
+                          d->dt = 0.05f; d->act_low = -1; d->act_high = 1; rc = 0; break;
     case REX_WALKER2D:    d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 13; d->frame_skip = 4;
-                          d->dt = 0.008f; d->act_low = -1; d->act_high = 1; return 0;
+                          d->dt = 0.008f; d->act_low = -1; d->act_high = 1; rc = 0; break;
     default: return -1;
+  }
+  if (rc == 0 && variant) {
+    if (variant != 1 || kind == REX_CARTPOLE) return -1;
+    d->task_dim = kind == REX_HOPPER ? 3 : (kind == REX_HALFCHEETAH ? 5 : 9);
+  }
+  return rc;
+}
+// Unmodeled ids: a prefix of xi is frozen and leaves the task vector
+// (random_hopper_unmodeled.py:28-30, random_half_cheetah_unmodeled.py:33-36, random_walker2d_unmodeled.py:38-41)
+static int variant_task_dim(int kind, int variant, int full) {
+  if (!variant) return full;
+  switch (kind) { case REX_HOPPER: return 3; case REX_HALFCHEETAH: return 5; case REX_WALKER2D: return 9; default: return -1; }
+}
+static void variant_map(int kind, int variant, int full, int* map) {
+  if (!variant) { for (int k = 0; k < full; k++) map[k] = k; return; }
+  switch (kind) {
+    case REX_HOPPER: for (int k = 0; k < 3; k++) map[k] = 1 + k; break;                 // thigh, leg, foot masses
+    case REX_HALFCHEETAH: for (int k = 0; k < 5; k++) map[k] = 3 + k; break;            // bfoot..ffoot masses, friction
+    case REX_WALKER2D: { const int m[9] = {3, 4, 5, 6, 8, 9, 10, 11, 12}; for (int k = 0; k < 9; k++) map[k] = m[k]; break; }
   }
 }
 
-extern "C" int rex_get_dims(int env_kind, rex_dims* out) {
+extern "C" int rex_get_dims(int env_kind, int variant, rex_dims* out) {
   if (!out) return set_err(REX_ERR_ARG, "rex_get_dims: null out");
   if (env_kind == REX_HUMANOID) return set_err(REX_ERR_UNSUPPORTED, "humanoid kernel not built yet");
-  if (fill_dims(env_kind, out)) return set_err(REX_ERR_ARG, "unknown env kind %d", env_kind);
+  if (fill_dims(env_kind, variant, out)) return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
   return REX_OK;
 }
 
@@ -432,9 +452,9 @@ static void sp_to_float(const SolParams<double>& a, SolParams<float>& b) {
 }
 
 template <class S>
-static void host_derive(rex_env* h, PlanarGeom<float, S>& out) {
+static void host_derive(rex_env* h, PlanarGeom<float, S>& out, const double* size_override = nullptr) {
   PlanarGeom<double, S> G; SolParams<double> sp; double nominal[S::NB]; double size[8];
-  for (int k = 0; k < S::NSIZE; k++) size[k] = S::default_size[k];
+  for (int k = 0; k < S::NSIZE; k++) size[k] = size_override ? size_override[k] : S::default_size[k];
   derive_model<double, S>(size, G, nominal, sp);
   to_float_geom<double, S>(G, out); sp_to_float(sp, h->sp);
   for (int b = 0; b < S::NB; b++) h->nominal_xi[b] = (float)nominal[b];
@@ -451,8 +471,9 @@ static int lanes_for(long long B) {
 }
 static unsigned grid_for(long long B) { int l = lanes_for(B); return (unsigned)((B + l - 1) / l); }
 
-static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st) {
-  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, st, h->dev, mask, bit);
+static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st, int task_changed) {
+  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, st, h->dev, mask, bit,
+                     (h->variant && task_changed) ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return REX_OK;
 }
@@ -462,9 +483,9 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (!out) return set_err(REX_ERR_ARG, "rex_create: null out");
   if (batch <= 0) return set_err(REX_ERR_ARG, "rex_create: batch must be > 0 (got %lld)", (long long)batch);
   if (env_kind == REX_HUMANOID) return set_err(REX_ERR_UNSUPPORTED, "humanoid kernel not built yet");
-  if (variant != 0) return set_err(REX_ERR_UNSUPPORTED, "unmodeled variants not built yet");
-  rex_dims dims;
-  if (fill_dims(env_kind, &dims)) return set_err(REX_ERR_ARG, "unknown env kind %d", env_kind);
+  rex_dims dims, full;
+  if (fill_dims(env_kind, variant, &dims) || fill_dims(env_kind, 0, &full))
+    return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
   HIP_TRY(hipSetDevice(device_id));
   rex_env* h = new (std::nothrow) rex_env();
   if (!h) return set_err(REX_ERR_ARG, "out of host memory");
@@ -472,13 +493,15 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   h->dims = dims;
   h->flags.endless = 0; h->flags.noisy = 0; h->flags.time_limit = 1; h->flags.max_steps = dims.max_episode_steps;
   h->flags.noise_std = 0.0f;
+  h->full_dim = full.task_dim;
   h->dr.type = REX_DR_NONE; h->dr.dim = dims.task_dim;
+  variant_map(env_kind, variant, full.task_dim, h->dr.map);
   const size_t B = (size_t)batch;
   DevState& d = h->dev;
   d.B = batch; d.env_offset = env_offset; d.seed = seed;
   HIP_TRY(hipMalloc(&d.qpos, sizeof(float) * dims.nq * B));
   HIP_TRY(hipMalloc(&d.qvel, sizeof(float) * dims.nv * B));
-  HIP_TRY(hipMalloc(&d.xi, sizeof(float) * dims.task_dim * B));
+  HIP_TRY(hipMalloc(&d.xi, sizeof(float) * full.task_dim * B));
   HIP_TRY(hipMalloc(&d.t, sizeof(int) * B));
   HIP_TRY(hipMalloc(&d.episode, sizeof(unsigned) * B));
   HIP_TRY(hipMalloc(&d.done, B));
@@ -494,12 +517,18 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   float noise_var = 0;
   switch (env_kind) {
     case REX_CARTPOLE: { const float t0[4] = {9.8f, 1.0f, 0.1f, 0.5f}; memcpy(h->nominal_xi, t0, sizeof t0); break; }   // random_cartpole.py:74-78
-    case REX_HOPPER: host_derive<HopperSpec>(h, h->g_hopper); noise_var = HopperSpec::DEFAULT_NOISE_VAR; break;
+    case REX_HOPPER: host_derive<HopperSpec>(h, h->g_hopper); noise_var = HopperSpec::DEFAULT_NOISE_VAR;
+                     if (variant) h->nominal_xi[0] *= 0.8f;                                                               // random_hopper_unmodeled.py:24-26
+                     break;
     case REX_HALFCHEETAH: host_derive<HalfCheetahSpec>(h, h->g_cheetah); h->nominal_xi[7] = 0.4f;                        // random_half_cheetah.py:37
+                          if (variant) for (int b = 0; b < 3; b++) h->nominal_xi[b] *= 0.8f;                             // random_half_cheetah_unmodeled.py:28-31
                           noise_var = HalfCheetahSpec::DEFAULT_NOISE_VAR; break;
     case REX_WALKER2D: {
-      host_derive<Walker2dSpec>(h, h->g_walker);
-      for (int k = 0; k < 4; k++) h->nominal_xi[7 + k] = (float)Walker2dSpec::default_size[k];                           // random_walker2d.py:21
+      double wsize[4]; for (int k = 0; k < 4; k++) wsize[k] = Walker2dSpec::default_size[k];
+      if (variant) wsize[0] *= 0.8;                                                                                      // random_walker2d_unmodeled.py:25-27
+      host_derive<Walker2dSpec>(h, h->g_walker, wsize);
+      if (variant) for (int b = 0; b < 3; b++) h->nominal_xi[b] *= 0.8f;                                                 // :33-36 (until the first set_task, Q6)
+      for (int k = 0; k < 4; k++) h->nominal_xi[7 + k] = (float)wsize[k];                                                // random_walker2d.py:21
       h->nominal_xi[11] = 0.9f; h->nominal_xi[12] = 1.9f;                                                                // random_walker2d.py:37
       HIP_TRY(hipMalloc(&d.geom, sizeof(float) * geom_floats<Walker2dSpec>() * B));
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
@@ -507,10 +536,10 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   h->flags.noise_std = sqrtf(noise_var);
   if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
   // xi <- nominal task, state <- qpos0
-  HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * dims.task_dim, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, dims.task_dim, (long long)B);
+  HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);
   HIP_TRY(hipGetLastError());
-  if (env_kind == REX_WALKER2D) { int rc = launch_walker_derive(h, nullptr, 0, 0); if (rc) return rc; }
+  if (env_kind == REX_WALKER2D) { int rc = launch_walker_derive(h, nullptr, 0, 0, 0); if (rc) return rc; }
   if (env_kind == REX_HOPPER || env_kind == REX_WALKER2D) {
     float q0[MAX_XI] = {0}; q0[1] = 1.25f;
     HIP_TRY(hipDeviceSynchronize());
@@ -583,7 +612,7 @@ static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, 
     case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
   }
   HIP_TRY(hipGetLastError());
-  if (h->kind == REX_WALKER2D && resample) return launch_walker_derive(h, mask, bit, st);
+  if (h->kind == REX_WALKER2D && resample) return launch_walker_derive(h, mask, bit, st, 1);
   return REX_OK;
 }
 
@@ -650,12 +679,18 @@ extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, voi
 }
 extern "C" int rex_get_task(rex_t* h, float* xi, void* stream) {
   if (!h || !xi) return set_err(REX_ERR_ARG, "rex_get_task: null argument");
-  return copy_rows(xi, h->dev.xi, h->dims.task_dim, h->B, (hipStream_t)stream);
+  for (int k = 0; k < h->dims.task_dim; k++) {   // task row k = row map[k] of the full xi block
+    int rc = copy_rows(xi + (size_t)k * h->B, h->dev.xi + (size_t)h->dr.map[k] * h->B, 1, h->B, (hipStream_t)stream); if (rc) return rc;
+  }
+  return REX_OK;
 }
 extern "C" int rex_set_task(rex_t* h, const float* xi, void* stream) {
   if (!h || !xi) return set_err(REX_ERR_ARG, "rex_set_task: null argument");
-  int rc = copy_rows(h->dev.xi, xi, h->dims.task_dim, h->B, (hipStream_t)stream); if (rc) return rc;
-  if (h->kind == REX_WALKER2D) return launch_walker_derive(h, nullptr, 0, (hipStream_t)stream);
+  int rc = REX_OK;
+  for (int k = 0; k < h->dims.task_dim; k++) {
+    rc = copy_rows(h->dev.xi + (size_t)h->dr.map[k] * h->B, xi + (size_t)k * h->B, 1, h->B, (hipStream_t)stream); if (rc) return rc;
+  }
+  if (h->kind == REX_WALKER2D) return launch_walker_derive(h, nullptr, 0, (hipStream_t)stream, 1);
   return REX_OK;
 }
 extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {

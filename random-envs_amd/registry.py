@@ -1,6 +1,6 @@
 """gym.make-style factory under the reference's ids (random_envs/__init__.py + the
 ``gym.envs.register`` calls at the bottom of every task file)."""
-from .specs import IDS, PENDING_IDS, SPECS
+from .specs import IDS, PENDING_IDS, SPECS, UNMODELED_SPECS
 
 
 def registered_ids():
@@ -10,7 +10,8 @@ def registered_ids():
 def spec(env_id):
     if env_id not in IDS:
         raise KeyError("No registered env with id: %s" % env_id)
-    return SPECS[IDS[env_id][0]]
+    kind, kw = IDS[env_id]
+    return UNMODELED_SPECS[kind] if kw.get("unmodeled") else SPECS[kind]
 
 
 def make(env_id, batch=1, device=0, seed=0, env_offset=0, **kwargs):

@@ -33,7 +33,7 @@ HOPPER = EnvSpec(                                     # random_envs/jinja/random
     search_bounds=[_M] * 4,                                                     # :52-57
     lower_bounds=[0.1] * 4,                                                     # :65-70
     # body_mass[1:] of the compiled hopper.xml under MuJoCo 2.1.0 (1000*pi*r^2*(L+r))
-    nominal_task=[3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 5.0893800988154645],
+    nominal_task=[3.5342917352885186, 3.9269908169872427, 2.7143360527015816, 5.0893800988154645],
     reward_threshold=1750, preferred_lr=0.0005, noise_level=1e-4,              # :44-45,28
     dr_on_reset=True)                                                           # :117-118
 
@@ -42,8 +42,8 @@ HALFCHEETAH = EnvSpec(                                # random_envs/jinja/random
     names=["torso", "bthigh", "bshin", "bfoot", "fthigh", "fshin", "ffoot", "friction"],   # :46
     search_bounds=[_M] * 7 + [(0.1, 2.0)],                                      # :55-64
     lower_bounds=[0.1] * 7 + [0.02],                                            # :72-81
-    nominal_task=[6.360313323782975, 1.5352480417754572, 1.5809399477806787, 1.0691906005221934,
-                  1.4255874673629243, 1.1788511749347258, 0.8498694516971279, 0.4],   # settotalmass=14; friction :37
+    nominal_task=[6.360313315926893, 1.5352480417754566, 1.5809399477806787, 1.069190600522193,
+                  1.425587467362924, 1.1788511749347257, 0.8498694516971277, 0.4],   # settotalmass=14; friction :37
     reward_threshold=4500, preferred_lr=0.0005, noise_level=1e-4,              # :48-49,30
     dr_on_reset=True)                                                           # :128-129
 
@@ -53,13 +53,43 @@ WALKER2D = EnvSpec(                                   # random_envs/jinja/random
            "torsosize", "thighsize", "legsize", "footsize", "friction_right", "friction_left"],   # :46
     search_bounds=[_M] * 7 + [(0.15, 1.0)] * 4 + [(0.1, 3.0)] * 2,              # :56-73
     lower_bounds=[0.1] * 7 + [0.1] * 4 + [0.05] * 2,                            # :80-96
-    nominal_task=[3.5342917352885173, 3.9269908169872414, 2.7143360527015816, 2.9405307237600464,
-                  3.9269908169872414, 2.7143360527015816, 2.9405307237600464,
+    nominal_task=[3.5342917352885186, 3.9269908169872427, 2.7143360527015816, 2.9405307237600464,
+                  3.9269908169872427, 2.7143360527015816, 2.9405307237600464,
                   0.4, 0.45, 0.6, 0.2, 0.9, 1.9],                               # :21,37
     reward_threshold=2200, preferred_lr=0.0005, noise_level=1e-3,              # :48-49,30
     dr_on_reset=True)                                                           # :145-146
 
+# ---- "Unmodeled" ids: a prefix of xi is frozen at 0.8x nominal and leaves the task vector ----------
+HOPPER_UNMODELED = EnvSpec(                           # random_envs/jinja/random_hopper_unmodeled.py
+    kind="hopper",
+    names=["thighmass", "legmass", "footmass"],                                 # :39
+    search_bounds=[_M] * 3,                                                     # :49-53
+    lower_bounds=[0.001] * 3,                                                   # :61-65
+    nominal_task=HOPPER.nominal_task[1:],                                       # :29 body_mass[2:]
+    reward_threshold=1750, preferred_lr=0.0005, noise_level=0.0,               # :41-42 (no noisy option)
+    dr_on_reset=True)                                                           # :110-111
+
+HALFCHEETAH_UNMODELED = EnvSpec(                      # random_envs/jinja/random_half_cheetah_unmodeled.py
+    kind="halfcheetah",
+    names=["bfoot", "fthigh", "fshin", "ffoot", "friction"],                    # :43
+    search_bounds=[_M] * 4 + [(0.1, 2.0)],                                      # :52-61
+    lower_bounds=[0.1] * 4 + [0.02],                                            # :69-78
+    nominal_task=HALFCHEETAH.nominal_task[3:],                                  # :33-34
+    reward_threshold=4500, preferred_lr=0.0005, noise_level=0.0,               # :45-46
+    dr_on_reset=True)
+
+WALKER2D_UNMODELED = EnvSpec(                         # random_envs/jinja/random_walker2d_unmodeled.py
+    kind="walker2d",
+    names=["foot", "thigh_left", "leg_left", "foot_left", "thighsize", "legsize", "footsize",
+           "friction_right", "friction_left"],                                  # :49
+    search_bounds=[_M] * 4 + [(0.3, 1.0), (0.3, 1.0), (0.15, 0.8)] + [(0.1, 3.0)] * 2,   # :59-76
+    lower_bounds=[0.1] * 4 + [0.25, 0.25, 0.12] + [0.05] * 2,                   # :84-100
+    nominal_task=WALKER2D.nominal_task[3:7] + [0.45, 0.6, 0.2, 0.9, 1.9],       # :38-40
+    reward_threshold=2200, preferred_lr=0.0005, noise_level=0.0,               # :51-52
+    dr_on_reset=True)
+
 SPECS = {"cartpole": CARTPOLE, "hopper": HOPPER, "halfcheetah": HALFCHEETAH, "walker2d": WALKER2D}
+UNMODELED_SPECS = {"hopper": HOPPER_UNMODELED, "halfcheetah": HALFCHEETAH_UNMODELED, "walker2d": WALKER2D_UNMODELED}
 
 # gym ids registered by the reference: id -> (kind, kwargs)
 IDS = {
@@ -70,8 +100,10 @@ IDS = {
     "RandomHalfCheetahNoisy-v0": ("halfcheetah", {"noisy": True}),   # :167-172
     "RandomWalker2d-v0": ("walker2d", {}),                       # random_walker2d.py:188-192
     "RandomWalker2dNoisy-v0": ("walker2d", {"noisy": True}),     # :194-199
+    "RandomHopperUnmodeled-v0": ("hopper", {"unmodeled": True}),             # random_hopper_unmodeled.py:146-150
+    "RandomHalfCheetahUnmodeled-v0": ("halfcheetah", {"unmodeled": True}),   # random_half_cheetah_unmodeled.py:155-159
+    "RandomWalker2dUnmodeled-v0": ("walker2d", {"unmodeled": True}),         # random_walker2d_unmodeled.py:187-191
 }
 # ids of the reference not built yet: creating them raises
-PENDING_IDS = ["RandomHumanoid-v0", "RandomHumanoidNoisy-v0", "RandomHopperUnmodeled-v0",
-               "RandomHalfCheetahUnmodeled-v0", "RandomWalker2dUnmodeled-v0", "RandomHumanoidUnmodeled-v0"]
+PENDING_IDS = ["RandomHumanoid-v0", "RandomHumanoidNoisy-v0", "RandomHumanoidUnmodeled-v0"]
 MAX_EPISODE_STEPS = 500

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _native
 from .dr import DRConfig
-from .specs import MAX_EPISODE_STEPS, SPECS
+from .specs import MAX_EPISODE_STEPS, SPECS, UNMODELED_SPECS
 
 
 class _Box:
@@ -31,20 +31,24 @@ class _Discrete:
 
 class VecRandomEnv(DRConfig):
     def __init__(self, kind, batch=1, device=0, seed=0, env_offset=0, noisy=False, env_id=None,
-                 autoreset=True, time_limit=True):
+                 autoreset=True, time_limit=True, unmodeled=False):
         import torch
         self._torch = torch
-        self.spec = SPECS[kind]
+        self.unmodeled = bool(unmodeled)
+        if self.unmodeled and noisy:
+            raise TypeError("the Unmodeled ids take no `noisy` argument (random_hopper_unmodeled.py:17)")
+        self.spec = UNMODELED_SPECS[kind] if self.unmodeled else SPECS[kind]
         self.kind, self.env_id = kind, env_id
         self.batch, self.num_envs = int(batch), int(batch)
         self.device = torch.device("cuda", device)
         L = _native.lib()   # raises loudly when the HIP library is missing
         dims = _native.RexDims()
-        _native.check(L.rex_get_dims(_native.ENV_KINDS[kind], ctypes.byref(dims)))
+        _native.check(L.rex_get_dims(_native.ENV_KINDS[kind], int(self.unmodeled), ctypes.byref(dims)))
         self.dims = dims
         self.task_dim = dims.task_dim
         self._h = ctypes.c_void_p()
-        _native.check(L.rex_create(_native.ENV_KINDS[kind], 0, self.batch, device, seed, env_offset, ctypes.byref(self._h)))
+        _native.check(L.rex_create(_native.ENV_KINDS[kind], int(self.unmodeled), self.batch, device, seed, env_offset,
+                                     ctypes.byref(self._h)))
         self._L = L
         DRConfig.__init__(self, self.spec)   # RandomEnv.__init__ state + per-env tables
         self.noisy = bool(noisy)

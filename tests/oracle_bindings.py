@@ -41,14 +41,19 @@ def _soa(x, dim):
     return np.ascontiguousarray(x.T)
 
 
-def oracle_batch_step(kind, qpos, qvel, action, xi, nthreads=8, tolerance=1e-12):
-    """One env.step() per row from (qpos, qvel, action, xi); all arrays [n, dim]."""
+UNMODELED_NX = {"hopper": 3, "halfcheetah": 5, "walker2d": 9}
+
+
+def oracle_batch_step(kind, qpos, qvel, action, xi, nthreads=8, tolerance=1e-12, variant=0):
+    """One env.step() per row from (qpos, qvel, action, xi); all arrays [n, dim].
+    variant=1: the Unmodeled id (xi is the reduced task; a NaN xi row keeps the freshly built model)."""
     d = DIMS[kind]; L = lib(); L.mjo_set_tolerance(tolerance)
-    q, v, a, x = _soa(qpos, d["nq"]), _soa(qvel, d["nv"]), _soa(action, d["nu"]), _soa(xi, d["nx"])
+    nx = UNMODELED_NX[kind] if variant else d["nx"]
+    q, v, a, x = _soa(qpos, d["nq"]), _soa(qvel, d["nv"]), _soa(action, d["nu"]), _soa(xi, nx)
     n = q.shape[1]
     qo = np.zeros_like(q); vo = np.zeros_like(v); obs = np.zeros((d["nobs"], n)); r = np.zeros(n)
     dn = np.zeros(n, dtype=np.uint8)
-    rc = L.mjo_batch_step(KINDS[kind], 0, n, _p(q), _p(v), _p(a), _p(x), _p(qo), _p(vo), _p(obs), _p(r),
+    rc = L.mjo_batch_step(KINDS[kind], int(variant), n, _p(q), _p(v), _p(a), _p(x), _p(qo), _p(vo), _p(obs), _p(r),
                           dn.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), nthreads)
     assert rc == 0
     return dict(qpos=qo.T.copy(), qvel=vo.T.copy(), obs=obs.T.copy(), reward=r, done=dn.astype(bool))

@@ -133,3 +133,46 @@ def test_full_batch_finite_and_deterministic(torch_mod, kind, B):
     o1, t1, c1 = run(); o2, t2, c2 = run()
     assert torch.equal(o1, o2) and t1 == t2
     assert c1["nonfinite"] == 0
+
+
+@pytest.mark.parametrize("kind,eid", [("hopper", "RandomHopperUnmodeled-v0"), ("halfcheetah", "RandomHalfCheetahUnmodeled-v0"),
+                                      ("walker2d", "RandomWalker2dUnmodeled-v0")])
+def test_unmodeled_ids(torch_mod, kind, eid):
+    """same kernels, reduced task vector, frozen 0.8x prefix (test.py's source env)."""
+    import random_envs_amd as rex
+    from oracle_bindings import DIMS, UNMODELED_NX, oracle_batch_step
+    torch = torch_mod
+    n = 512; d = DIMS[kind]; nx = UNMODELED_NX[kind]
+    env = rex.make(eid, batch=n, seed=3, autoreset=False)
+    assert env.task_dim == nx and len(env.dyn_ind_to_name) == nx
+    nom = np.array(env.original_task)
+    assert np.allclose(env.get_task().cpu().numpy(), nom[None], rtol=1e-6)
+    rng = np.random.RandomState(1)
+    q = rng.uniform(-.005, .005, (n, d["nq"])); v = rng.uniform(-.3, .3, (n, d["nv"]))
+    if kind != "halfcheetah":
+        q[:, 1] += 1.25
+    a = rng.uniform(-1, 1, (n, d["nu"]))
+    q, v, a = [x.astype(np.float32).astype(np.float64) for x in (q, v, a)]
+    # (1) freshly constructed env (no set_task yet): frozen prefix at 0.8x nominal
+    env.set_state(q, v)
+    obs, r, dn, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+    ref = oracle_batch_step(kind, q, v, a, np.full((n, nx), np.nan), variant=1)
+    e0 = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    assert np.percentile(e0, 99) < 2e-4, e0.max()
+    # (2) after set_task with a random reduced task
+    lo = np.array([b[0] for b in env.spec.search_bounds]); hi = np.array([b[1] for b in env.spec.search_bounds])
+    xi = (nom * rng.uniform(0.8, 1.2, (n, nx))).clip(lo, hi).astype(np.float32).astype(np.float64)
+    env.set_task(xi.astype(np.float32)); env.set_state(q, v)
+    assert np.allclose(env.get_task().cpu().numpy(), xi, rtol=1e-6)
+    obs, r, dn, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+    ref = oracle_batch_step(kind, q, v, a, xi, variant=1)
+    e1 = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    assert np.percentile(e1, 99) < 2e-4, e1.max()
+    # (3) test.py's scenario: uniform DR on the source env, then reset resamples only the reduced task
+    env.set_dr_distribution("uniform", np.stack([lo * 1.1, np.minimum(hi, lo * 1.1 + 1.0)], 1).ravel().tolist())
+    env.set_dr_training(True); env.reset()
+    t = env.get_task().cpu().numpy()
+    assert (t >= lo * 1.1 - 1e-6).all() and (t <= np.minimum(hi, lo * 1.1 + 1.0) + 1e-6).all()
+    obs, r, dn, _ = env.step(torch.zeros(n, d["nu"]))
+    assert torch.isfinite(obs).all()
+    env.close()

@@ -65,3 +65,38 @@ def test_xi_changes_mass_not_inertia():
     M1 = oracle_forward("hopper", q, v, a, xi)["M"]; M2 = oracle_forward("hopper", q, v, a, 2 * xi)["M"]
     assert not np.allclose(M2, 2 * M1) and np.allclose(M2[0, 0], 2 * M1[0, 0])
     assert not np.allclose(a2[3:], a1[3:] / 2, rtol=1e-3)
+
+
+def test_unmodeled_variants_oracle_semantics():
+    """Unmodeled ids: frozen 0.8x prefix, reduced task; Walker2d loses the 0.8x mass
+    scaling at the first set_task because the model is rebuilt."""
+    import ctypes
+    from oracle_bindings import lib, KINDS, _p
+    L = lib()
+    from random_envs_amd.specs import SPECS, UNMODELED_SPECS
+    rng = np.random.RandomState(0)
+    # hopper: stepping the unmodeled env with xi_r == stepping the regular env with [0.8*m0, xi_r]
+    q = rng.uniform(-.01, .01, (8, 6)); q[:, 1] += 1.25; v = rng.uniform(-.5, .5, (8, 6)); a = rng.uniform(-1, 1, (8, 3))
+    xr = np.array(UNMODELED_SPECS["hopper"].nominal_task) * rng.uniform(.8, 1.2, (8, 3))
+    full = np.concatenate([np.full((8, 1), 0.8 * SPECS["hopper"].nominal_task[0]), xr], 1)
+    o1 = oracle_batch_step("hopper", q, v, a, xr, variant=1); o0 = oracle_batch_step("hopper", q, v, a, full)
+    assert np.allclose(o1["qvel"], o0["qvel"], rtol=1e-12, atol=1e-12)
+    # cheetah
+    q = rng.uniform(-.1, .1, (8, 9)); v = rng.uniform(-.5, .5, (8, 9)); a = rng.uniform(-1, 1, (8, 6))
+    xr = np.array(UNMODELED_SPECS["halfcheetah"].nominal_task) * rng.uniform(.8, 1.2, (8, 5))
+    full = np.concatenate([np.tile(0.8 * np.array(SPECS["halfcheetah"].nominal_task[:3]), (8, 1)), xr], 1)
+    o1 = oracle_batch_step("halfcheetah", q, v, a, xr, variant=1); o0 = oracle_batch_step("halfcheetah", q, v, a, full)
+    assert np.allclose(o1["qvel"], o0["qvel"], rtol=1e-12, atol=1e-12)
+    # walker: after set_task the frozen masses are the geometry masses of (0.32, thighsize, legsize) -- NOT 0.8x
+    q = rng.uniform(-.005, .005, (4, 9)); q[:, 1] += 1.25; v = rng.uniform(-.5, .5, (4, 9)); a = rng.uniform(-1, 1, (4, 6))
+    xr = np.tile(np.array(UNMODELED_SPECS["walker2d"].nominal_task), (4, 1)); xr[:, 4] = [0.45, 0.5, 0.4, 0.45]
+    geo = [oracle_constants("walker2d", size=[0.32, xr[i, 4], xr[i, 5], xr[i, 6]])["body_mass"][1:4] for i in range(4)]
+    full = np.concatenate([np.array(geo), xr[:, :4], np.full((4, 1), 0.32), xr[:, 4:]], 1)
+    o1 = oracle_batch_step("walker2d", q, v, a, xr, variant=1); o0 = oracle_batch_step("walker2d", q, v, a, full)
+    assert np.allclose(o1["qvel"], o0["qvel"], rtol=1e-12, atol=1e-12)
+    # ... and before any set_task they ARE 0.8x (NaN xi keeps the fresh model)
+    geo0 = oracle_constants("walker2d", size=[0.32, 0.45, 0.6, 0.2])["body_mass"][1:]
+    full0 = np.concatenate([0.8 * geo0[:3], geo0[3:], [0.32, 0.45, 0.6, 0.2, 0.9, 1.9]])[None].repeat(4, 0)
+    o1 = oracle_batch_step("walker2d", q, v, a, np.full((4, 9), np.nan), variant=1)
+    o0 = oracle_batch_step("walker2d", q, v, a, full0)
+    assert np.allclose(o1["qvel"], o0["qvel"], rtol=1e-12, atol=1e-12)
