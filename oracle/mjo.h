@@ -25,10 +25,10 @@ extern "C" {
 #define MJO_MAXQ 26
 #define MJO_MAXV 24
 #define MJO_MAXGEOM 24
-#define MJO_MAXPAIR 96
+#define MJO_MAXPAIR 256
 #define MJO_MAXU 20
-#define MJO_MAXCON 64
-#define MJO_MAXEFC 256
+#define MJO_MAXCON 96
+#define MJO_MAXEFC 320
 
 enum { MJO_JNT_FREE = 0, MJO_JNT_SLIDE = 2, MJO_JNT_HINGE = 3 };
 enum { MJO_GEOM_PLANE = 0, MJO_GEOM_SPHERE = 2, MJO_GEOM_CAPSULE = 3 };
@@ -109,6 +109,10 @@ typedef struct mjoData {
   int efc_id[MJO_MAXEFC];
   int solver_iter;
   double energy[2];
+  /* com-based quantities of the humanoid observation ([3P] mj_comPos / mj_comVel): subtree COM of the
+   * root body, per-body cinert (10) and cvel (6) */
+  double subtree_com_root[3];
+  double cinert[MJO_MAXBODY][10], cvel[MJO_MAXBODY][6];
 } mjoData;
 
 /* ---- model builders: restate the reference's MJCF templates ---------------------------- */
@@ -124,6 +128,7 @@ void mjo_forward(const mjoModel* m, mjoData* d);
 void mjo_step(const mjoModel* m, mjoData* d);
 /* total mechanical energy (potential, kinetic) for self-consistency tests */
 void mjo_energy(const mjoModel* m, mjoData* d);
+void mjo_com_quantities(const mjoModel* m, mjoData* d);
 
 /* ---- env-level oracle: one reference env object (task definition files) ---------------- */
 typedef struct mjoEnv {
@@ -133,6 +138,8 @@ typedef struct mjoEnv {
   mjoModel model;
   mjoData data;
   double size[8];
+  double xipos_x_prev[MJO_MAXBODY];   /* humanoid: data.xipos[:,0] of the last mj_forward */
+  int xipos_valid;
 } mjoEnv;
 
 int mjo_env_init(mjoEnv* e, int kind, int variant);
@@ -167,6 +174,13 @@ int mjo_model_constants(int kind, const double* size, double* body_mass, double*
 
 /* parity tests tighten the Newton tolerance (default: the model's 1e-8) */
 void mjo_set_tolerance(double tol);
+
+/* Humanoid env step (random_humanoid.py:161-216). xipos_x_prev [14][n]: data.xipos[:,0] left by the previous
+ * mj_forward (mass_center() reads it BEFORE do_simulation); a NaN entry means "state was just set"
+ * (set_state runs sim.forward(), jinja_mujoco_env.py:146-154).  obs_out [376][n]. */
+int mjo_humanoid_batch_step(int n, const double* qpos, const double* qvel, const double* action, const double* xi,
+                            const double* xipos_x_prev, double* qpos_out, double* qvel_out, double* obs_out,
+                            double* reward_out, unsigned char* done_out, double* xipos_x_out, int nthreads);
 
 /* CartPole closed-form step (random_envs/random_cartpole.py:172-224) */
 void mjo_cartpole_step(const double* state, int action, const double* xi, double* next_state,

@@ -297,7 +297,11 @@ static void compile_pairs(mjoModel* m) {
   /* weld ids: a body without joints is welded to its parent ([3P] body_weldid) */
   m->body_weldid[0] = 0;
   for (int b = 1; b < m->nbody; b++) m->body_weldid[b] = m->body_jntnum[b] ? b : m->body_weldid[m->body_parent[b]];
-  for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+  /* [3P] mj_collision walks body pairs sorted by (body1 << 16) + body2 and, inside a pair, geoms of body1 x
+   * geoms of body2: the contact (hence PGS row) order follows from that */
+  for (int bb1 = 0; bb1 < m->nbody; bb1++) for (int bb2 = bb1 + 1; bb2 < m->nbody; bb2++)
+  for (int g1 = 0; g1 < m->ngeom; g1++) for (int g2 = 0; g2 < m->ngeom; g2++) {
+    if (m->geom_body[g1] != bb1 || m->geom_body[g2] != bb2) continue;
     int a = g1, b = g2;
     if (m->geom_type[a] > m->geom_type[b]) { int t = a; a = b; b = t; }
     int b1 = m->geom_body[a], b2 = m->geom_body[b];
@@ -1156,4 +1160,113 @@ int mjo_build_halfcheetah(mjoModel* m, const double* size) {
   add_pair(m, footg[0], floor, 3, fr); add_pair(m, footg[1], floor, 3, fr); /* :129-132 */
   compile(m, 14.0);                                             /* settotalmass="14" :54 */
   return 0;
+}
+
+
+/* random_envs/jinja/assets/humanoid.xml (local coordinates, angles in degrees, inertiafromgeom) */
+int mjo_build_humanoid(mjoModel* m) {
+  model_init(m);
+  m->timestep = 0.003; m->integrator = MJO_INT_RK4; m->solver = MJO_SOL_PGS; m->iterations = 50;   /* humanoid.xml:9 */
+  JntDef jd; jntdef_init(&jd); jd.armature = 1; jd.damping = 1; jd.limited = 1;                      /* :4 */
+  JntDef root = jd; root.armature = 0; root.damping = 0; root.limited = 0; root.stiffness = 0;         /* :32 */
+  GeomDef gd; geomdef_init(&gd); gd.conaffinity = 1; gd.condim = 1; gd.contype = 1; gd.margin = 0.001; /* :5 */
+  GeomDef fl = gd; fl.condim = 3; fl.friction[0] = 1; fl.friction[1] = .1; fl.friction[2] = .1;        /* :28 */
+  add_plane(m, &fl);
+  double O[3] = {0, 0, 0};
+  struct J { const char* name; double arm, ax[3], damp, pos[3], lo, hi, stiff; };
+#define JNT(body, A, X, Y, Z, D, PX, PY, PZ, LO, HI, K) do { JntDef t = jd; t.armature = A; t.damping = D; t.stiffness = K; \
+    double ax_[3] = {X, Y, Z}, ps_[3] = {PX, PY, PZ}; jn[nj++] = add_joint(m, body, MJO_JNT_HINGE, ps_, ax_, 0, &t, 1, (LO) * DEG, (HI) * DEG); } while (0)
+  int jn[17], nj = 0;
+  double p[3], f[3], t[3], q[4];
+  p[0] = 0; p[1] = 0; p[2] = 1.4;
+  int torso = add_body(m, 0, p, NULL);                                                                  /* :30 */
+  add_joint(m, torso, MJO_JNT_FREE, O, NULL, 0, &root, 0, 0, 0);                                        /* :32 */
+#define V3(v, a, b, c) do { v[0] = a; v[1] = b; v[2] = c; } while (0)
+  V3(f, 0, -.07, 0); V3(t, 0, .07, 0); add_capsule_fromto(m, torso, f, t, 0.07, &gd);                   /* :33 */
+  V3(p, 0, 0, .19); add_sphere(m, torso, p, .09, &gd);                                                  /* :34 */
+  V3(f, -.01, -.06, -.12); V3(t, -.01, .06, -.12); add_capsule_fromto(m, torso, f, t, 0.06, &gd);       /* :35 */
+  q[0] = 1.0; q[1] = 0; q[2] = -0.002; q[3] = 0;
+  V3(p, -.01, 0, -0.260); int lwaist = add_body(m, torso, p, q);                                        /* :36 */
+  V3(f, 0, -.06, 0); V3(t, 0, .06, 0); add_capsule_fromto(m, lwaist, f, t, 0.06, &gd);                  /* :37 */
+  JNT(lwaist, 0.02, 0, 0, 1, 5, 0, 0, 0.065, -45, 45, 20);                                              /* abdomen_z :38 */
+  JNT(lwaist, 0.02, 0, 1, 0, 5, 0, 0, 0.065, -75, 30, 10);                                              /* abdomen_y :39 */
+  V3(p, 0, 0, -0.165); int pelvis = add_body(m, lwaist, p, q);                                          /* :40 */
+  JNT(pelvis, 0.02, 1, 0, 0, 5, 0, 0, 0.1, -35, 35, 10);                                                /* abdomen_x :41 */
+  V3(f, -.02, -.07, 0); V3(t, -.02, .07, 0); add_capsule_fromto(m, pelvis, f, t, 0.09, &gd);            /* butt :42 */
+  /* right leg :43-56 */
+  V3(p, 0, -0.1, -0.04); int rthigh = add_body(m, pelvis, p, NULL);
+  JNT(rthigh, 0.01, 1, 0, 0, 5, 0, 0, 0, -25, 5, 10);                                                   /* right_hip_x */
+  JNT(rthigh, 0.01, 0, 0, 1, 5, 0, 0, 0, -60, 35, 10);                                                  /* right_hip_z */
+  JNT(rthigh, 0.0080, 0, 1, 0, 5, 0, 0, 0, -110, 20, 20);                                               /* right_hip_y */
+  V3(f, 0, 0, 0); V3(t, 0, 0.01, -.34); add_capsule_fromto(m, rthigh, f, t, 0.06, &gd);
+  V3(p, 0, 0.01, -0.403); int rshin = add_body(m, rthigh, p, NULL);
+  JNT(rshin, 0.0060, 0, -1, 0, 1, 0, 0, .02, -160, -2, 0);                                              /* right_knee (default damping 1) */
+  V3(f, 0, 0, 0); V3(t, 0, 0, -.3); add_capsule_fromto(m, rshin, f, t, 0.049, &gd);
+  V3(p, 0, 0, -0.45); int rfoot = add_body(m, rshin, p, NULL);
+  V3(p, 0, 0, 0.1); add_sphere(m, rfoot, p, 0.075, &gd);
+  /* left leg :57-70 */
+  V3(p, 0, 0.1, -0.04); int lthigh = add_body(m, pelvis, p, NULL);
+  JNT(lthigh, 0.01, -1, 0, 0, 5, 0, 0, 0, -25, 5, 10);                                                  /* left_hip_x */
+  JNT(lthigh, 0.01, 0, 0, -1, 5, 0, 0, 0, -60, 35, 10);                                                 /* left_hip_z */
+  JNT(lthigh, 0.01, 0, 1, 0, 5, 0, 0, 0, -110, 20, 20);                                                 /* left_hip_y */
+  V3(f, 0, 0, 0); V3(t, 0, -0.01, -.34); add_capsule_fromto(m, lthigh, f, t, 0.06, &gd);
+  V3(p, 0, -0.01, -0.403); int lshin = add_body(m, lthigh, p, NULL);
+  JNT(lshin, 0.0060, 0, -1, 0, 1, 0, 0, .02, -160, -2, 1);                                              /* left_knee stiffness 1 */
+  V3(f, 0, 0, 0); V3(t, 0, 0, -.3); add_capsule_fromto(m, lshin, f, t, 0.049, &gd);
+  V3(p, 0, 0, -0.45); int lfoot = add_body(m, lshin, p, NULL);
+  V3(p, 0, 0, 0.1); add_sphere(m, lfoot, p, 0.075, &gd);
+  /* arms :72-91 */
+  V3(p, 0, -0.17, 0.06); int ruarm = add_body(m, torso, p, NULL);
+  JNT(ruarm, 0.0068, 2, 1, 1, 1, 0, 0, 0, -85, 60, 1);                                                  /* right_shoulder1 */
+  JNT(ruarm, 0.0051, 0, -1, 1, 1, 0, 0, 0, -85, 60, 1);                                                 /* right_shoulder2 */
+  V3(f, 0, 0, 0); V3(t, .16, -.16, -.16); add_capsule_fromto(m, ruarm, f, t, 0.04, &gd);
+  V3(p, .18, -.18, -.18); int rlarm = add_body(m, ruarm, p, NULL);
+  JNT(rlarm, 0.0028, 0, -1, 1, 1, 0, 0, 0, -90, 50, 0);                                                 /* right_elbow */
+  V3(f, .01, .01, .01); V3(t, .17, .17, .17); add_capsule_fromto(m, rlarm, f, t, 0.031, &gd);
+  V3(p, .18, .18, .18); add_sphere(m, rlarm, p, 0.04, &gd);
+  V3(p, 0, 0.17, 0.06); int luarm = add_body(m, torso, p, NULL);
+  JNT(luarm, 0.0068, 2, -1, 1, 1, 0, 0, 0, -60, 85, 1);                                                 /* left_shoulder1 */
+  JNT(luarm, 0.0051, 0, 1, 1, 1, 0, 0, 0, -60, 85, 1);                                                  /* left_shoulder2 */
+  V3(f, 0, 0, 0); V3(t, .16, .16, -.16); add_capsule_fromto(m, luarm, f, t, 0.04, &gd);
+  V3(p, .18, .18, -.18); int llarm = add_body(m, luarm, p, NULL);
+  JNT(llarm, 0.0028, 0, -1, -1, 1, 0, 0, 0, -90, 50, 0);                                                /* left_elbow */
+  V3(f, .01, -.01, .01); V3(t, .17, -.17, .17); add_capsule_fromto(m, llarm, f, t, 0.031, &gd);
+  V3(p, .18, -.18, .18); add_sphere(m, llarm, p, 0.04, &gd);
+  /* motors :106-122 -- note the order: abdomen_y, abdomen_z, abdomen_x, ... */
+  static const int order[17] = {1, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+  static const double gear[17] = {100, 100, 100, 100, 100, 300, 200, 100, 100, 300, 200, 25, 25, 25, 25, 25, 25};
+  for (int k = 0; k < 17; k++) add_motor(m, jn[order[k]], gear[k], -0.4, 0.4);                          /* ctrlrange :6 */
+  compile(m, 0);
+  return 0;
+#undef JNT
+#undef V3
+}
+
+/* [3P] mj_comPos / mj_comVel quantities entering the humanoid observation: cinert (rotational inertia about
+ * the root's subtree COM in world axes, mass*offset, mass) and cvel (spatial velocity referred to that point).
+ * subtree COM uses the CURRENT body_mass but the compile-time body_subtreemass (not refreshed by set_task). */
+void mjo_com_quantities(const mjoModel* m, mjoData* d) {
+  double sc[3] = {0, 0, 0};
+  for (int b = 1; b < m->nbody; b++) addscl3(sc, d->xipos[b], m->body_mass[b]);
+  double sm = m->body_subtreemass[1];      /* root body = torso (body 1) */
+  if (sm < MINVAL) copy3(sc, d->xipos[1]); else { sc[0] /= sm; sc[1] /= sm; sc[2] /= sm; }
+  copy3(d->subtree_com_root, sc);
+  memset(d->cinert[0], 0, sizeof d->cinert[0]); memset(d->cvel[0], 0, sizeof d->cvel[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    const double* R = d->xmat[b]; double Iw[9], RI[9], dif[3], mass = m->body_mass[b];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R[i * 3 + k] * m->body_inertia[b][k * 3 + j]; RI[i * 3 + j] = s; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += RI[i * 3 + k] * R[j * 3 + k]; Iw[i * 3 + j] = s; }
+    sub3(dif, d->xipos[b], sc);
+    double* c = d->cinert[b];
+    c[0] = Iw[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    c[1] = Iw[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    c[2] = Iw[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    c[3] = Iw[1] - mass * dif[0] * dif[1];
+    c[4] = Iw[2] - mass * dif[0] * dif[2];
+    c[5] = Iw[5] - mass * dif[1] * dif[2];
+    c[6] = mass * dif[0]; c[7] = mass * dif[1]; c[8] = mass * dif[2]; c[9] = mass;
+    /* bvel = (w; v at world origin)  ->  v at sc = v_O + w x sc */
+    double t[3]; cross3(t, d->bvel[b], sc);
+    copy3(d->cvel[b], d->bvel[b]); add3(d->cvel[b] + 3, d->bvel[b] + 3, t);
+  }
 }

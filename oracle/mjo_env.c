@@ -38,6 +38,10 @@ int mjo_env_init(mjoEnv* e, int kind, int variant) {
       e->frame_skip = 5; e->obs_dim = 17; e->task_dim = variant ? 5 : 8; e->act_dim = 6;
       if (variant) for (int b = 1; b <= 3; b++) e->model.body_mass[b] *= 0.8;   /* random_half_cheetah_unmodeled.py:28-31 */
       break;
+    case MJO_ENV_HUMANOID:    /* random_humanoid.py:41 frame_skip 5; obs 376; xi = 13 masses + 17 dampings */
+      if (variant) return -1;
+      mjo_build_humanoid(&e->model);
+      e->frame_skip = 5; e->obs_dim = 376; e->task_dim = 30; e->act_dim = 17; break;
     default: return -1;
   }
   mjo_reset_data(&e->model, &e->data);
@@ -76,6 +80,10 @@ void mjo_env_get_task(const mjoEnv* e, double* xi) {
       for (int i = 0; i < 7; i++) xi[i] = m->body_mass[1 + i];
       for (int i = 0; i < 4; i++) xi[7 + i] = e->size[i];
       xi[11] = m->pair_friction[0][0]; xi[12] = m->pair_friction[1][0]; break;
+    case MJO_ENV_HUMANOID:    /* random_humanoid.py:151-154 */
+      for (int i = 0; i < 13; i++) xi[i] = m->body_mass[1 + i];
+      for (int i = 0; i < 17; i++) xi[13 + i] = m->dof_damping[6 + i];
+      break;
   }
 }
 
@@ -119,6 +127,10 @@ void mjo_env_set_task(mjoEnv* e, const double* xi) {
       mjo_reset_data(m, &e->data);
       (void)qpos; (void)qvel;
       break; }
+    case MJO_ENV_HUMANOID:    /* random_humanoid.py:156-158 */
+      for (int i = 0; i < 13; i++) m->body_mass[1 + i] = xi[i];
+      for (int i = 0; i < 17; i++) m->dof_damping[6 + i] = xi[13 + i];
+      break;
   }
 }
 
@@ -126,9 +138,22 @@ void mjo_env_set_state(mjoEnv* e, const double* qpos, const double* qvel) {
   /* MujocoEnv.set_state (jinja_mujoco_env.py:146-154) */
   memcpy(e->data.qpos, qpos, sizeof(double) * e->model.nq);
   memcpy(e->data.qvel, qvel, sizeof(double) * e->model.nv);
+  e->xipos_valid = 0;   /* set_state runs sim.forward(): done lazily by the humanoid step */
+}
+
+static void humanoid_obs(mjoEnv* e, double* obs) {   /* random_humanoid.py:190-216 (noise-free) */
+  mjoData* d = &e->data; int c = 0;
+  mjo_com_quantities(&e->model, d);
+  for (int k = 2; k < 24; k++) obs[c++] = d->qpos[k];
+  for (int k = 0; k < 23; k++) obs[c++] = d->qvel[k];
+  for (int b = 0; b < 14; b++) for (int k = 0; k < 10; k++) obs[c++] = d->cinert[b][k];
+  for (int b = 0; b < 14; b++) for (int k = 0; k < 6; k++) obs[c++] = d->cvel[b][k];
+  for (int k = 0; k < 23; k++) obs[c++] = d->qfrc_actuator[k];
+  for (int k = 0; k < 84; k++) obs[c++] = 0.0;   /* cfrc_ext, SURVEY Q15 */
 }
 
 void mjo_env_obs(const mjoEnv* e, double* obs) {
+  if (e->kind == MJO_ENV_HUMANOID) { humanoid_obs((mjoEnv*)e, obs); return; }
   /* _get_obs: concat(qpos[1:], qvel) -- random_hopper.py:100-110, random_half_cheetah.py:112-121,
    * random_walker2d.py:133-142 (noise is added by the caller, it is not part of the oracle) */
   int nq = e->model.nq, nv = e->model.nv;
@@ -139,6 +164,19 @@ void mjo_env_obs(const mjoEnv* e, double* obs) {
 int mjo_env_step(mjoEnv* e, const double* a, double* obs, double* reward) {
   mjoModel* m = &e->model; mjoData* d = &e->data;
   if (g_tolerance > 0) m->tolerance = g_tolerance;
+  if (e->kind == MJO_ENV_HUMANOID) {   /* random_humanoid.py:161-188 */
+    if (!e->xipos_valid) { mjo_forward(m, d); for (int b = 0; b < m->nbody; b++) e->xipos_x_prev[b] = d->xipos[b][0]; e->xipos_valid = 1; }
+    double s0 = 0, s1 = 0, mt = 0, asq = 0;
+    for (int b = 0; b < m->nbody; b++) { s0 += m->body_mass[b] * e->xipos_x_prev[b]; mt += m->body_mass[b]; }
+    for (int u = 0; u < m->nu; u++) { d->ctrl[u] = a[u]; asq += a[u] * a[u]; }
+    for (int k = 0; k < e->frame_skip; k++) mjo_step(m, d);
+    for (int b = 0; b < m->nbody; b++) { e->xipos_x_prev[b] = d->xipos[b][0]; s1 += m->body_mass[b] * d->xipos[b][0]; }
+    *reward = 1.25 * (s1 / mt - s0 / mt) / (m->timestep * e->frame_skip) - 0.1 * asq + 5.0;
+    int dn = (d->qpos[2] < 1.0) || (d->qpos[2] > 2.0);
+    if (e->endless) dn = 0;
+    if (obs) humanoid_obs(e, obs);
+    return dn;
+  }
   double posbefore = d->qpos[0];
   /* do_simulation (jinja_mujoco_env.py:170-173) */
   for (int u = 0; u < m->nu; u++) d->ctrl[u] = a[u];
@@ -182,7 +220,7 @@ static void* batch_worker(void* arg) {
   mjoEnv* e = (mjoEnv*)malloc(sizeof(mjoEnv));
   mjo_env_init(e, j->kind, j->variant);
   int nq = e->model.nq, nv = e->model.nv, nu = e->act_dim, nx = e->task_dim, n = j->n;
-  double q[MJO_MAXQ], v[MJO_MAXV], a[MJO_MAXU], xi[32], last_xi[32], obs[64];
+  double q[MJO_MAXQ], v[MJO_MAXV], a[MJO_MAXU], xi[32], last_xi[32], obs[384];
   int have_xi = 0;
   for (int i = j->lo; i < j->hi; i++) {
     for (int k = 0; k < nx; k++) xi[k] = j->xi[(size_t)k * n + i];

@@ -25,6 +25,7 @@
 
 #include "../../include/rex.h"
 #include "planar_model.hpp"
+#include "humanoid_model.hpp"
 
 using namespace rex;
 
@@ -123,6 +124,7 @@ __device__ void sample_task(const DRParams& dr, rocrand_state_philox4x32_10* st,
 struct DevState {
   float* qpos; float* qvel; float* xi;     // SoA rows of length B
   float* geom;                             // walker2d: per-env PlanarGeom rows [NGEOMF][B]; else null
+  float* aux;                              // humanoid: data.xipos[:,0] of the last forward, [14][B]; else null
   int* t; unsigned* episode; unsigned char* done;
   unsigned long long* counters;            // [4]
   long long B, env_offset;
@@ -371,6 +373,116 @@ __global__ void fill_rows_kernel(float* dst, const float* vals, int nrows, long 
 }
 
 // ------------------------------------------------------------------------------------------
+// Humanoid (random_envs/jinja/random_humanoid.py).  One env per lane; the per-lane working set of a
+// forward evaluation (hum::Scratch, ~20 KB: M 23x23, J and M^-1 J^T for up to 64 rows, contact list)
+// lives in HIP scratch memory, lane-interleaved so every access of a wave is one coalesced segment.
+// The compiled model is uniform and sits in __constant__ memory.
+// ------------------------------------------------------------------------------------------
+__constant__ hum::Model<float> c_hum;
+
+__device__ __forceinline__ void hum_lane(const DevState& s, unsigned i, hum::Lane<float>& L) {
+  // set_task (random_humanoid.py:156-158): body_mass[1:] = xi[:13]; dof_damping[6:] = xi[13:]
+  L.mass[0] = 0.0f;
+  for (int k = 0; k < 13; k++) L.mass[1 + k] = (s.xi + (size_t)k * s.B)[i];
+  for (int d = 0; d < 6; d++) L.damping[d] = 0.0f;
+  for (int k = 0; k < 17; k++) L.damping[6 + k] = (s.xi + (size_t)(13 + k) * s.B)[i];
+}
+
+__global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags fl, const float* __restrict__ action,
+                                                           float* __restrict__ obs, float* __restrict__ reward,
+                                                           unsigned char* __restrict__ done_out, unsigned char* __restrict__ trunc_out,
+                                                           float* __restrict__ term_obs) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.B) return;
+  const size_t B = (size_t)s.B;
+  hum::Lane<float> L; hum_lane(s, i, L);
+  float q[hum::NQ], v[hum::NV], a[hum::NU], xp[hum::NBODY];
+  for (int k = 0; k < hum::NQ; k++) q[k] = (s.qpos + k * B)[i];
+  for (int k = 0; k < hum::NV; k++) v[k] = (s.qvel + k * B)[i];
+  for (int k = 0; k < hum::NU; k++) a[k] = (action + k * B)[i];
+  for (int b = 0; b < hum::NBODY; b++) xp[b] = (s.aux + b * B)[i];
+  hum::Scratch<float> sc;
+  float r; bool dn;
+  rocrand_state_philox4x32_10 st;
+  int t = s.t[i] + 1;
+  if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
+                             (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
+  hum::env_step(c_hum, L, q, v, a, xp, sc, r, dn, [&](int k, float val) {
+    // noise only on the qpos / qvel slices (random_humanoid.py:193-204)
+    if (fl.noisy && k < 45) val += fl.noise_std * rocrand_normal(&st);
+    (obs + k * B)[i] = val;
+    if (term_obs) (term_obs + k * B)[i] = val;
+  });
+  bool finite = true;
+  for (int k = 0; k < hum::NQ; k++) finite = finite && isfinite(q[k]);
+  for (int k = 0; k < hum::NV; k++) finite = finite && isfinite(v[k]);
+  if (!finite) { atomicAdd(s.counters + 0, 1ull); dn = true; }     // a diverged lane ends its episode
+  if (sc.overflow) atomicAdd(s.counters + 3, 1ull);
+  if (fl.endless && finite) dn = false;
+  s.t[i] = t;
+  bool trunc = fl.time_limit && t >= fl.max_steps && !dn;
+  bool d = dn || trunc;
+  for (int k = 0; k < hum::NQ; k++) (s.qpos + k * B)[i] = q[k];
+  for (int k = 0; k < hum::NV; k++) (s.qvel + k * B)[i] = v[k];
+  for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
+  s.done[i] = d ? 2 : 0;
+  reward[i] = r; done_out[i] = d ? 1 : 0;
+  if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+}
+
+// reset_model (random_humanoid.py:219-234): init noise U(-.01,.01) on all of qpos (incl. the quaternion) and qvel,
+// set_state -> sim.forward() with the CURRENT task, THEN set_random_task (the cinert block of the
+// returned observation is computed with the previous episode's masses).
+__global__ void __launch_bounds__(64) humanoid_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
+                                                            const unsigned char* __restrict__ mask, int mask_bit,
+                                                            float* __restrict__ obs) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.B) return;
+  if (mask && !(mask[i] & mask_bit)) return;
+  const size_t B = (size_t)s.B;
+  unsigned ep = s.episode[i] + 1; s.episode[i] = ep;
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
+  if (reset_state) {
+    float q[hum::NQ], v[hum::NV], xp[hum::NBODY];
+    for (int k = 0; k < hum::NQ; k++) q[k] = c_hum.qpos0[k] + 0.01f * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
+    for (int k = 0; k < hum::NV; k++) v[k] = 0.01f * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
+    hum::Lane<float> L; hum_lane(s, i, L);
+    hum::Scratch<float> sc;
+    rocrand_state_philox4x32_10 st2;
+    if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + STEP_BASE, &st2);
+    hum::env_reset_obs(c_hum, L, q, v, xp, sc, [&](int k, float val) {
+      if (fl.noisy && k < 45) val += fl.noise_std * rocrand_normal(&st2);
+      if (obs) (obs + k * B)[i] = val;
+    });
+    for (int k = 0; k < hum::NQ; k++) (s.qpos + k * B)[i] = q[k];
+    for (int k = 0; k < hum::NV; k++) (s.qvel + k * B)[i] = v[k];
+    for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
+    s.t[i] = 0; s.done[i] = 0;
+  }
+  if (resample && dr.type != REX_DR_NONE) {
+    rocrand_state_philox4x32_10 st3;
+    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, &st3);
+    float xi[MAX_XI]; sample_task(dr, &st3, xi, s.counters);
+    for (int k = 0; k < dr.dim; k++) (s.xi + (size_t)dr.map[k] * B)[i] = xi[k];
+  }
+}
+
+// set_state / get_obs: sim.forward() at the stored state (jinja_mujoco_env.py:146-154)
+__global__ void __launch_bounds__(64) humanoid_forward_kernel(DevState s, float* __restrict__ obs) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.B) return;
+  const size_t B = (size_t)s.B;
+  float q[hum::NQ], v[hum::NV], xp[hum::NBODY];
+  for (int k = 0; k < hum::NQ; k++) q[k] = (s.qpos + k * B)[i];
+  for (int k = 0; k < hum::NV; k++) v[k] = (s.qvel + k * B)[i];
+  hum::Lane<float> L; hum_lane(s, i, L);
+  hum::Scratch<float> sc;
+  hum::env_reset_obs(c_hum, L, q, v, xp, sc, [&](int k, float val) { if (obs) (obs + k * B)[i] = val; });
+  for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side handle
 // ------------------------------------------------------------------------------------------
 struct rex_env {
@@ -410,10 +522,12 @@ static int fill_dims(int kind, int variant, rex_dims* d) {
                           d->dt = 0.05f; d->act_low = -1; d->act_high = 1; rc = 0; break;
     case REX_WALKER2D:    d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 13; d->frame_skip = 4;
                           d->dt = 0.008f; d->act_low = -1; d->act_high = 1; rc = 0; break;
+    case REX_HUMANOID:    d->nq = 24; d->nv = 23; d->act_dim = 17; d->obs_dim = 376; d->task_dim = 30; d->frame_skip = 5;
+                          d->dt = 0.015f; d->act_low = -0.4f; d->act_high = 0.4f; rc = 0; break;   // humanoid.xml:6,9; random_humanoid.py:41
     default: return -1;
   }
   if (rc == 0 && variant) {
-    if (variant != 1 || kind == REX_CARTPOLE) return -1;
+    if (variant != 1 || kind == REX_CARTPOLE || kind == REX_HUMANOID) return -1;   // RandomHumanoidUnmodeled-v0: not built yet
     d->task_dim = kind == REX_HOPPER ? 3 : (kind == REX_HALFCHEETAH ? 5 : 9);
   }
   return rc;
@@ -435,7 +549,6 @@ static void variant_map(int kind, int variant, int full, int* map) {
 
 extern "C" int rex_get_dims(int env_kind, int variant, rex_dims* out) {
   if (!out) return set_err(REX_ERR_ARG, "rex_get_dims: null out");
-  if (env_kind == REX_HUMANOID) return set_err(REX_ERR_UNSUPPORTED, "humanoid kernel not built yet");
   if (fill_dims(env_kind, variant, out)) return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
   return REX_OK;
 }
@@ -482,7 +595,6 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
                           rex_t** out) {
   if (!out) return set_err(REX_ERR_ARG, "rex_create: null out");
   if (batch <= 0) return set_err(REX_ERR_ARG, "rex_create: batch must be > 0 (got %lld)", (long long)batch);
-  if (env_kind == REX_HUMANOID) return set_err(REX_ERR_UNSUPPORTED, "humanoid kernel not built yet");
   rex_dims dims, full;
   if (fill_dims(env_kind, variant, &dims) || fill_dims(env_kind, 0, &full))
     return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
@@ -513,7 +625,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   HIP_TRY(hipMemset(d.episode, 0, sizeof(unsigned) * B));
   HIP_TRY(hipMemset(d.done, 0, B));
   HIP_TRY(hipMemset(d.counters, 0, sizeof(unsigned long long) * 4));
-  d.geom = nullptr;
+  d.geom = nullptr; d.aux = nullptr;
   float noise_var = 0;
   switch (env_kind) {
     case REX_CARTPOLE: { const float t0[4] = {9.8f, 1.0f, 0.1f, 0.5f}; memcpy(h->nominal_xi, t0, sizeof t0); break; }   // random_cartpole.py:74-78
@@ -532,6 +644,16 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       h->nominal_xi[11] = 0.9f; h->nominal_xi[12] = 1.9f;                                                                // random_walker2d.py:37
       HIP_TRY(hipMalloc(&d.geom, sizeof(float) * geom_floats<Walker2dSpec>() * B));
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
+    case REX_HUMANOID: {
+      static hum::Model<double> md; static hum::Model<float> mf; static bool built = false;
+      if (!built) { hum::build_model(md); hum::convert_model(md, mf); built = true; }
+      HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hum), &mf, sizeof mf));
+      for (int b = 0; b < 13; b++) h->nominal_xi[b] = (float)md.body_mass0[1 + b];          // random_humanoid.py:46
+      for (int k = 0; k < 17; k++) h->nominal_xi[13 + k] = (float)md.dof_damping0[6 + k];   // :47
+      HIP_TRY(hipMalloc(&d.aux, sizeof(float) * hum::NBODY * B));
+      HIP_TRY(hipMemset(d.aux, 0, sizeof(float) * hum::NBODY * B));
+      noise_var = 1e-3f;                                                                      // :39
+      break; }
   }
   h->flags.noise_std = sqrtf(noise_var);
   if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
@@ -540,6 +662,15 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);
   HIP_TRY(hipGetLastError());
   if (env_kind == REX_WALKER2D) { int rc = launch_walker_derive(h, nullptr, 0, 0, 0); if (rc) return rc; }
+  if (env_kind == REX_HUMANOID) {
+    float q0[MAX_XI] = {0}; q0[2] = 1.4f; q0[3] = 1.0f;                                       // humanoid.xml:30,32
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->d_scratch, q0, sizeof(float) * dims.nq, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.qpos, h->d_scratch, dims.nq, (long long)B);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, 0, h->dev, (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
   if (env_kind == REX_HOPPER || env_kind == REX_WALKER2D) {
     float q0[MAX_XI] = {0}; q0[1] = 1.25f;
     HIP_TRY(hipDeviceSynchronize());
@@ -559,6 +690,7 @@ extern "C" int rex_destroy(rex_t* h) {
   hipFree(h->dev.qpos); hipFree(h->dev.qvel); hipFree(h->dev.xi); hipFree(h->dev.t); hipFree(h->dev.episode);
   hipFree(h->dev.done); hipFree(h->dev.counters); hipFree(h->d_scratch);
   if (h->dev.geom) hipFree(h->dev.geom);
+  if (h->dev.aux) hipFree(h->dev.aux);
   for (auto e : h->ev0) hipEventDestroy(e);
   for (auto e : h->ev1) hipEventDestroy(e);
   delete h;
@@ -610,6 +742,7 @@ static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, 
     case REX_HOPPER: hipLaunchKernelGGL(planar_reset_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
     case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_reset_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
     case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_reset_kernel, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
   }
   HIP_TRY(hipGetLastError());
   if (h->kind == REX_WALKER2D && resample) return launch_walker_derive(h, mask, bit, st, 1);
@@ -650,6 +783,8 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
       hipLaunchKernelGGL(planar_step_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->g_cheetah, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
     case REX_WALKER2D:
       hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+    case REX_HUMANOID:
+      hipLaunchKernelGGL(humanoid_step_kernel, g, b, 0, st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
   }
   if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
   HIP_TRY(hipGetLastError());
@@ -675,6 +810,10 @@ extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, voi
   int rc = copy_rows(h->dev.qpos, qpos, h->dims.nq, h->B, (hipStream_t)stream); if (rc) return rc;
   rc = copy_rows(h->dev.qvel, qvel, h->dims.nv, h->B, (hipStream_t)stream); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(h->dev.done, 0, (size_t)h->B, (hipStream_t)stream));   // steps_beyond_done = None
+  if (h->kind == REX_HUMANOID) {   // set_state runs sim.forward(): refreshes data.xipos (jinja_mujoco_env.py:154)
+    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, (hipStream_t)stream, h->dev, (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
   return REX_OK;
 }
 extern "C" int rex_get_task(rex_t* h, float* xi, void* stream) {
@@ -701,6 +840,7 @@ extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
     case REX_HOPPER: hipLaunchKernelGGL(planar_obs_kernel<HopperSpec>, g, b, 0, st, h->dev, obs_out); break;
     case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_obs_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, obs_out); break;
     case REX_WALKER2D: hipLaunchKernelGGL(planar_obs_kernel<Walker2dSpec>, g, b, 0, st, h->dev, obs_out); break;
+    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_forward_kernel, g, b, 0, st, h->dev, obs_out); break;
   }
   HIP_TRY(hipGetLastError());
   return REX_OK;

@@ -59,6 +59,19 @@ WALKER2D = EnvSpec(                                   # random_envs/jinja/random
     reward_threshold=2200, preferred_lr=0.0005, noise_level=1e-3,              # :48-49,30
     dr_on_reset=True)                                                           # :145-146
 
+HUMANOID = EnvSpec(                                   # random_envs/jinja/random_humanoid.py
+    kind="humanoid",
+    names=["mass%d" % i for i in range(13)] + ["damp%d" % i for i in range(1, 18)],   # :55-61
+    search_bounds=[_M] * 13 + [(1, 10.0)] * 6 + [(.2, 5.0)] + [(1, 10.0)] * 3 + [(.2, 5.0)] * 7,   # :72-105 (damp7, damp11-17 -> (.2,5))
+    lower_bounds=[0.2] * 13 + [0.8] * 6 + [.15] + [0.8] * 3 + [.15] * 7,          # :113-146
+    # body_mass[1:] of humanoid.xml under MuJoCo 2.1.0 (capsules 1000*pi*r^2*(L+r)) + dof_damping[6:] (humanoid.xml:38-86)
+    nominal_task=[8.322078939359361, 2.035752039526186, 5.852787113637785, 4.525556257747776, 2.6324944224829134,
+                  1.7671458676442582, 4.525556257747776, 2.6324944224829134, 1.7671458676442582, 1.5940598415616263,
+                  1.1983431305833825, 1.5940598415616263, 1.1983431305833825,
+                  5, 5, 5, 5, 5, 5, 1, 5, 5, 5, 1, 1, 1, 1, 1, 1, 1],
+    reward_threshold=2200, preferred_lr=0.0001, noise_level=1e-3,              # :63-64,39
+    dr_on_reset=True)                                                           # :231-232
+
 # ---- "Unmodeled" ids: a prefix of xi is frozen at 0.8x nominal and leaves the task vector ----------
 HOPPER_UNMODELED = EnvSpec(                           # random_envs/jinja/random_hopper_unmodeled.py
     kind="hopper",
@@ -88,7 +101,7 @@ WALKER2D_UNMODELED = EnvSpec(                         # random_envs/jinja/random
     reward_threshold=2200, preferred_lr=0.0005, noise_level=0.0,               # :51-52
     dr_on_reset=True)
 
-SPECS = {"cartpole": CARTPOLE, "hopper": HOPPER, "halfcheetah": HALFCHEETAH, "walker2d": WALKER2D}
+SPECS = {"cartpole": CARTPOLE, "hopper": HOPPER, "halfcheetah": HALFCHEETAH, "walker2d": WALKER2D, "humanoid": HUMANOID}
 UNMODELED_SPECS = {"hopper": HOPPER_UNMODELED, "halfcheetah": HALFCHEETAH_UNMODELED, "walker2d": WALKER2D_UNMODELED}
 
 # gym ids registered by the reference: id -> (kind, kwargs)
@@ -100,10 +113,12 @@ IDS = {
     "RandomHalfCheetahNoisy-v0": ("halfcheetah", {"noisy": True}),   # :167-172
     "RandomWalker2d-v0": ("walker2d", {}),                       # random_walker2d.py:188-192
     "RandomWalker2dNoisy-v0": ("walker2d", {"noisy": True}),     # :194-199
+    "RandomHumanoid-v0": ("humanoid", {}),                                   # random_humanoid.py:273-277
+    "RandomHumanoidNoisy-v0": ("humanoid", {"noisy": True}),                 # :279-284
     "RandomHopperUnmodeled-v0": ("hopper", {"unmodeled": True}),             # random_hopper_unmodeled.py:146-150
     "RandomHalfCheetahUnmodeled-v0": ("halfcheetah", {"unmodeled": True}),   # random_half_cheetah_unmodeled.py:155-159
     "RandomWalker2dUnmodeled-v0": ("walker2d", {"unmodeled": True}),         # random_walker2d_unmodeled.py:187-191
 }
 # ids of the reference not built yet: creating them raises
-PENDING_IDS = ["RandomHumanoid-v0", "RandomHumanoidNoisy-v0", "RandomHumanoidUnmodeled-v0"]
+PENDING_IDS = ["RandomHumanoidUnmodeled-v0"]
 MAX_EPISODE_STEPS = 500

@@ -9,7 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.path.join(ROOT, "oracle", "_build", "libmjo.so")
 KINDS = {"cartpole": 0, "hopper": 1, "halfcheetah": 2, "walker2d": 3, "humanoid": 4}
-DIMS = {"hopper": dict(nq=6, nv=6, nu=3, nx=4, nobs=11, frame_skip=4),
+DIMS = {"humanoid": dict(nq=24, nv=23, nu=17, nx=30, nobs=376, frame_skip=5),
+        "hopper": dict(nq=6, nv=6, nu=3, nx=4, nobs=11, frame_skip=4),
         "walker2d": dict(nq=9, nv=9, nu=6, nx=13, nobs=17, frame_skip=4),
         "halfcheetah": dict(nq=9, nv=9, nu=6, nx=8, nobs=17, frame_skip=5)}
 _D = ctypes.POINTER(ctypes.c_double)
@@ -92,6 +93,21 @@ def oracle_contacts(kind, qpos, qvel, xi):
     x = np.ascontiguousarray(xi, dtype=np.float64); out = np.zeros(10 * 32)
     n = L.mjo_probe_contacts(KINDS[kind], _p(q), _p(v), _p(x), _p(out), 32)
     return out.reshape(32, 10)[:n].copy()
+
+
+def oracle_humanoid_step(qpos, qvel, action, xi, xipos_x_prev=None, nthreads=8):
+    """RandomHumanoidEnv.step from (qpos[n,24], qvel[n,23], action[n,17], xi[n,30]); xipos_x_prev [n,14] or None
+    (None: the state was just set -> sim.forward())."""
+    L = lib()
+    q, v, a, x = _soa(qpos, 24), _soa(qvel, 23), _soa(action, 17), _soa(xi, 30)
+    n = q.shape[1]
+    xp = None if xipos_x_prev is None else _soa(xipos_x_prev, 14)
+    qo = np.zeros_like(q); vo = np.zeros_like(v); obs = np.zeros((376, n)); r = np.zeros(n); dn = np.zeros(n, dtype=np.uint8)
+    xo = np.zeros((14, n))
+    rc = L.mjo_humanoid_batch_step(n, _p(q), _p(v), _p(a), _p(x), _p(xp), _p(qo), _p(vo), _p(obs), _p(r),
+                                   dn.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _p(xo), nthreads)
+    assert rc == 0
+    return dict(qpos=qo.T.copy(), qvel=vo.T.copy(), obs=obs.T.copy(), reward=r, done=dn.astype(bool), xipos_x=xo.T.copy())
 
 
 def oracle_constants(kind, size=None):

@@ -1,0 +1,102 @@
+"""Humanoid HIP kernels (through the C-ABI) vs the fp64 oracle: 376-dim observation, reward with
+mass_center(), done; reset semantics; BASELINE config 5 shape (uniform 30-dim xi inside the search bounds)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _states(n, seed):
+    from random_envs_amd.specs import SPECS
+    rng = np.random.RandomState(seed)
+    nom = np.array(SPECS["humanoid"].nominal_task)
+    q = np.tile(np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float), (n, 1)) + rng.uniform(-.01, .01, (n, 24))
+    q[:, 7:] += rng.uniform(-.3, .3, (n, 17)); q[:, 2] = rng.uniform(1.0, 1.45, n)
+    v = rng.uniform(-1, 1, (n, 23)); a = rng.uniform(-.5, .5, (n, 17)); xi = nom * rng.uniform(.8, 1.2, (n, 30))
+    return [x.astype(np.float32).astype(np.float64) for x in (q, v, a, xi)]
+
+
+def test_step_parity_and_second_step(torch_mod):
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_humanoid_step
+    torch = torch_mod
+    n = 1024
+    q, v, a, xi = _states(n, 3)
+    env = rex.make("RandomHumanoid-v0", batch=n, autoreset=False)
+    assert env.task_dim == 30 and env.dims.obs_dim == 376 and env.dims.act_dim == 17
+    env.set_task(xi.astype(np.float32)); env.set_state(q, v)
+    obs, r, d, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+    ref = oracle_humanoid_step(q, v, a, xi)
+    o = obs.cpu().numpy().astype(np.float64)
+    eo = np.abs(o - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    qq, vv = env.get_state()
+    ev = np.abs(vv.cpu().numpy() - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    # stated fp32 tolerance for the humanoid (PGS capped at 50 sweeps amplifies rounding): p99 < 5e-4, median < 2e-5
+    assert np.percentile(ev, 99) < 5e-4 and np.median(ev) < 2e-5, (np.percentile(ev, 99), ev.max())
+    assert np.percentile(eo, 99) < 2e-4, (np.percentile(eo, 99), eo.max())
+    er = np.abs(r.cpu().numpy() - ref["reward"])
+    assert np.percentile(er, 99) < 2e-3
+    assert (d.cpu().numpy() != ref["done"]).mean() < 0.005
+    assert np.all(o[:, 292:] == 0)                                   # cfrc_ext block
+    # second step: mass_center() "before" comes from the xipos the previous step left behind
+    a2 = np.random.RandomState(9).uniform(-.4, .4, (n, 17)).astype(np.float32).astype(np.float64)
+    q1, v1 = qq.cpu().numpy().astype(np.float64), vv.cpu().numpy().astype(np.float64)
+    obs2, r2, d2, _ = env.step(torch.as_tensor(a2, dtype=torch.float32))
+    ref2 = oracle_humanoid_step(q1, v1, a2, xi, xipos_x_prev=ref["xipos_x"])
+    er2 = np.abs(r2.cpu().numpy() - ref2["reward"])
+    assert np.percentile(er2, 99) < 5e-3, np.percentile(er2, 99)
+    c = env.counters(); assert c["nonfinite"] == 0
+    env.close()
+
+
+def test_reset_dr_and_rollout_config5(torch_mod):
+    """BASELINE config 5 shape on one GPU shard: uniform 30-dim xi inside the search bounds, U(-0.4,0.4) actions."""
+    import random_envs_amd as rex
+    torch = torch_mod
+    B = 4096
+    env = rex.make("RandomHumanoid-v0", batch=B, seed=11)
+    lo, hi = env.get_task_search_bounds()
+    env.set_dr_distribution("uniform", np.stack([lo, hi], 1).ravel().tolist())
+    env.set_dr_training(True)
+    obs = env.reset()
+    assert obs.shape == (B, 376) and torch.isfinite(obs).all()
+    xi = env.get_task().cpu().numpy()
+    assert (xi >= lo - 1e-5).all() and (xi <= hi + 1e-5).all() and np.abs(xi.mean(0) - (lo + hi) / 2).max() < 0.15 * (hi - lo).max()
+    q, v = env.get_state()
+    q0 = np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17)
+    assert np.abs(q.cpu().numpy() - q0).max() <= 0.01 + 1e-6 and np.abs(v.cpu().numpy()).max() <= 0.01 + 1e-7   # random_humanoid.py:220-229
+    g = torch.Generator().manual_seed(0); ndone = 0
+    for t in range(30):
+        obs, r, d, info = env.step(torch.rand(B, 17, generator=g) * 0.8 - 0.4)
+        assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+        ndone += int(d.sum())
+        if d.any():
+            z = info["terminal_observation"][d][:, 0]
+            assert ((z < 1.0) | (z > 2.0)).all()                     # done = z < 1 or z > 2 (random_humanoid.py:173)
+            assert (obs[d][:, 0] - 1.4).abs().max() <= 0.01 + 1e-5   # auto-reset lanes restart near qpos0
+    assert ndone > 0
+    c = env.counters(); assert c["nonfinite"] == 0
+    env.close()
+
+
+def test_noisy_humanoid_only_noises_qpos_qvel(torch_mod):
+    import random_envs_amd as rex
+    torch = torch_mod
+    B = 2048
+    clean = rex.make("RandomHumanoid-v0", batch=B, seed=5, autoreset=False)
+    noisy = rex.make("RandomHumanoidNoisy-v0", batch=B, seed=5, autoreset=False)
+    clean.reset(); noisy.reset()
+    q, v = clean.get_state(); noisy.set_state(q, v)
+    a = torch.zeros(B, 17)
+    oc = clean.step(a)[0]; on = noisy.step(a)[0]
+    diff = (on - oc).cpu().numpy()
+    assert abs(diff[:, :45].std() - np.sqrt(1e-3)) < 2e-3            # sigma = sqrt(1e-3) (random_humanoid.py:39,193-204)
+    assert np.abs(diff[:, 45:]).max() == 0
+    clean.close(); noisy.close()

@@ -1,0 +1,95 @@
+"""Humanoid: the kernels' math (random-envs_amd/csrc/humanoid_engine.hpp: MuJoCo-style com-based CRB / RNE,
+incremental PGS) compiled for the host, against the independent 3-D oracle (world-frame Jacobian sums,
+dual PGS with an explicit A matrix)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_bindings import _p, lib, oracle_energy_drift, oracle_humanoid_step
+from random_envs_amd.specs import SPECS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "host_harness", "_build_humanoid_host.so")
+SRC = os.path.join(HERE, "host_harness", "humanoid_host.cpp")
+DEPS = [SRC] + [os.path.join(os.path.dirname(HERE), "random-envs_amd", "csrc", f) for f in
+                ("humanoid_engine.hpp", "humanoid_model.hpp", "planar_spec.hpp")]
+
+
+@pytest.fixture(scope="module")
+def hh():
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO, SRC])
+    return ctypes.CDLL(SO)
+
+
+def _states(n, seed, spread=0.3):
+    rng = np.random.RandomState(seed)
+    nom = np.array(SPECS["humanoid"].nominal_task)
+    q = np.tile(np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float), (n, 1)) + rng.uniform(-.01, .01, (n, 24))
+    q[:, 7:] += rng.uniform(-spread, spread, (n, 17)); q[:, 2] = rng.uniform(1.0, 1.45, n)
+    v = rng.uniform(-1, 1, (n, 23)); a = rng.uniform(-.5, .5, (n, 17)); xi = nom * rng.uniform(.8, 1.2, (n, 30))
+    return q, v, a, xi
+
+
+def test_published_masses_and_model_compiler(hh):
+    """12 of the 13 body masses equal the public mujoco-py-era Humanoid-v2 constants (2.1.0 capsule volume);
+    the pelvis value recalled for that table (6.61619413) is the exact-capsule one and is not asserted."""
+    mass = np.zeros(14); ib = np.zeros(28); idf = np.zeros(23); ipos = np.zeros(42); inr = np.zeros(84); npair = ctypes.c_int()
+    hh.hh_constants(_p(mass), _p(ib), _p(idf), _p(ipos), _p(inr), ctypes.byref(npair))
+    pub = [8.32207894, 2.03575204, None, 4.52555626, 2.63249442, 1.76714587, 4.52555626, 2.63249442, 1.76714587,
+           1.59405984, 1.19834313, 1.59405984, 1.19834313]
+    for k, p in enumerate(pub):
+        if p is not None:
+            assert abs(mass[1 + k] - p) < 5e-9
+    assert np.allclose(mass[1:], SPECS["humanoid"].nominal_task[:13], rtol=1e-13)
+    bm = np.zeros(14); nc = ctypes.c_int()
+    n_or = lib().mjo_humanoid_probe(None, None, None, None, _p(bm), None, None, ctypes.byref(nc), ctypes.byref(nc), ctypes.byref(nc), None, None, 0)
+    assert n_or == npair.value == 126 and np.allclose(bm, mass, rtol=1e-13)
+
+
+def test_oracle_energy_conservation_3d():
+    rng = np.random.RandomState(0)
+    q = np.array([0, 0, 3.0, 1, 0, 0, 0] + [0] * 17, dtype=float); q[7:] += rng.uniform(-.3, .3, 17)
+    qq = rng.randn(4); q[3:7] = qq / np.linalg.norm(qq)
+    e0, e1 = oracle_energy_drift("humanoid", 100, q, rng.uniform(-1, 1, 23))
+    assert abs(e1 - e0) < 1e-6 * abs(e0)
+
+
+def test_forward_dynamics_fp64(hh):
+    """qacc incl. un-converged PGS iterates (same row order => same sweep sequence) to rounding."""
+    O = lib(); rng = np.random.RandomState(0)
+    nom = np.array(SPECS["humanoid"].nominal_task); worst = 0; ncon_seen = 0
+    for _ in range(120):
+        q = np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float); q[7:] += rng.uniform(-.4, .4, 17); q[2] = rng.uniform(0.9, 1.5)
+        qq = np.array([1, 0, 0, 0]) + rng.uniform(-.3, .3, 4); q[3:7] = qq / np.linalg.norm(qq)
+        v = rng.uniform(-2, 2, 23); a = rng.uniform(-.5, .5, 17); xi = nom * rng.uniform(.7, 1.3, 30)
+        qa_o = np.zeros(23); M_o = np.zeros((23, 23)); nc, ne, it = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        O.mjo_humanoid_probe(_p(q), _p(v), _p(a), _p(xi), None, _p(qa_o), _p(M_o), ctypes.byref(nc), ctypes.byref(ne), ctypes.byref(it), None, None, 0)
+        qa_h = np.zeros(23); M_h = np.zeros((23, 23)); info = np.zeros(4, dtype=np.int32)
+        hh.hh_forward(0, _p(q), _p(v), _p(a), _p(xi), _p(qa_h), _p(M_h), info.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        assert info[0] == nc.value and info[1] == ne.value and info[3] == 0
+        assert np.abs(M_o - M_h).max() < 1e-12
+        worst = max(worst, np.abs(qa_o - qa_h).max() / (1 + np.abs(qa_o).max())); ncon_seen += nc.value
+    assert worst < 1e-9 and ncon_seen > 50
+
+
+def test_env_step_obs_reward(hh):
+    n = 200
+    q, v, a, xi = _states(n, 1)
+    ref = oracle_humanoid_step(q, v, a, xi)
+    UB = ctypes.POINTER(ctypes.c_ubyte); I = ctypes.POINTER(ctypes.c_int)
+    qs, vs, as_, xs = [np.ascontiguousarray(x.T) for x in (q, v, a, xi)]
+    for f32, tv, to in ((0, 1e-11, 1e-11), (1, 1e-4, 2e-5)):
+        qo = np.zeros_like(qs); vo = np.zeros_like(vs); obs = np.zeros((376, n)); r = np.zeros(n); d = np.zeros(n, dtype=np.uint8)
+        xo = np.zeros((14, n)); ov = np.zeros(n, dtype=np.int32)
+        hh.hh_step(f32, n, _p(qs), _p(vs), _p(as_), _p(xs), None, _p(qo), _p(vo), _p(obs), _p(r), d.ctypes.data_as(UB), _p(xo), ov.ctypes.data_as(I))
+        ev = np.abs(vo.T - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+        eo = np.abs(obs.T - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+        assert ev.max() < tv and eo.max() < to and ov.sum() == 0, (f32, ev.max(), eo.max())
+        assert np.abs(r - ref["reward"]).max() < (1e-10 if not f32 else 1e-4)
+        assert np.array_equal(d.astype(bool), ref["done"])
+    # the obs layout: 22 + 23 + 140 + 84 + 23 + 84 (random_humanoid.py:207-216); cfrc_ext block is zero
+    assert ref["obs"].shape[1] == 376 and np.all(ref["obs"][:, 292:] == 0) and np.all(ref["obs"][:, 45:55] == 0)
