@@ -29,10 +29,11 @@ ENV_ID = "RandomHopper-v0"
 BATCH_PER_GPU = 32768
 # algorithmic bytes per env-step = read (qpos,qvel,action,xi) + write (qpos,qvel,obs,reward,done)
 BYTES_PER_ENV_STEP = {"RandomHopper-v0": 173, "RandomWalker2d-v0": 293, "RandomHalfCheetah-v0": 273,
-                      "RandomHalfCheetahNoisy-v0": 273, "RandomCartPole-v0": 73}
+                      "RandomHalfCheetahNoisy-v0": 273, "RandomCartPole-v0": 73, "RandomHumanoid-v0": 2073}
 KERNEL_NAME = {"RandomHopper-v0": "planar_step_kernel<HopperSpec>", "RandomWalker2d-v0": "planar_step_kernel<Walker2dSpec>",
                "RandomHalfCheetah-v0": "planar_step_kernel<HalfCheetahSpec>",
-               "RandomHalfCheetahNoisy-v0": "planar_step_kernel<HalfCheetahSpec>", "RandomCartPole-v0": "cartpole_step_kernel"}
+               "RandomHalfCheetahNoisy-v0": "planar_step_kernel<HalfCheetahSpec>", "RandomCartPole-v0": "cartpole_step_kernel",
+               "RandomHumanoid-v0": "humanoid_step_kernel"}
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 NOMINAL = [3.5342917352885186, 3.9269908169872427, 2.7143360527015816, 5.0893800988154645]
@@ -93,7 +94,8 @@ def main():
     env.reset()
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     nact = 16
-    actions = [(torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1).cuda(local_rank).contiguous() for _ in range(nact)]
+    amp = float(env.dims.act_high)   # U(-1,1) (hopper/walker/cheetah) or U(-0.4,0.4) (humanoid, humanoid.xml:6)
+    actions = [((torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1) * amp).cuda(local_rank).contiguous() for _ in range(nact)]
 
     def sync():
         sharding.barrier()
