@@ -36,31 +36,40 @@ KERNEL_NAME = {"RandomHopper-v0": "planar_step_kernel<HopperSpec>", "RandomWalke
                "RandomHumanoid-v0": "humanoid_step_kernel"}
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
-NOMINAL = [3.5342917352885186, 3.9269908169872427, 2.7143360527015816, 5.0893800988154645]
 
 
-def cpu_baseline(batch, steps, seed=0, min_seconds=12.0):
+def cpu_baseline(env_id, batch, steps, seed=0, min_seconds=12.0):
     """oracle ("port") timed on the host cores: `batch` envs x `steps` env-steps from reset states."""
     import numpy as np
-    from oracle_bindings import oracle_rollout
+    from oracle_bindings import DIMS, oracle_rollout
+    from random_envs_amd.registry import spec as env_spec
+    from random_envs_amd.specs import IDS
+    kind = IDS[env_id][0]
+    d = DIMS[kind]; nominal = np.array(env_spec(env_id).nominal_task)
     cores = len(os.sched_getaffinity(0))
     rng = np.random.RandomState(seed)
-    q = rng.uniform(-.005, .005, (batch, 6)); q[:, 1] += 1.25
-    v = rng.uniform(-.005, .005, (batch, 6))
-    xi = np.array(NOMINAL) * rng.uniform(0.9, 1.1, (batch, 4))
-    acts = rng.uniform(-1, 1, (steps, batch, 3))
-    oracle_rollout("hopper", q[:64], v[:64], acts[:2, :64], xi[:64], nthreads=cores)   # warm the library
+    if kind == "humanoid":
+        q = np.tile(np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float), (batch, 1)) + rng.uniform(-.01, .01, (batch, 24))
+        v = rng.uniform(-.01, .01, (batch, 23)); amp = 0.4
+    elif kind == "halfcheetah":
+        q = rng.uniform(-.1, .1, (batch, 9)); v = 0.1 * rng.randn(batch, 9); amp = 1.0
+    else:
+        q = rng.uniform(-.005, .005, (batch, d["nq"])); q[:, 1] += 1.25
+        v = rng.uniform(-.005, .005, (batch, d["nv"])); amp = 1.0
+    xi = nominal * rng.uniform(0.9, 1.1, (batch, d["nx"]))
+    acts = rng.uniform(-amp, amp, (steps, batch, d["nu"]))
+    oracle_rollout(kind, q[:64], v[:64], acts[:2, :64], xi[:64], nthreads=cores)   # warm the library
     # bounded sample: repeat the (batch x steps) rollout from the reset states until >= min_seconds
     # of wall time has been spent (MuJoCo's own solver tolerance 1e-8)
     reps, dt = 0, 0.0
     t0 = time.perf_counter()
     while dt < min_seconds and reps < 64:
-        oracle_rollout("hopper", q, v, acts, xi, nthreads=cores)
+        oracle_rollout(kind, q, v, acts, xi, nthreads=cores)
         reps += 1; dt = time.perf_counter() - t0
     steps = steps * reps
     return dict(value=batch * steps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d env-steps (%d-step rollouts from reset states, %d repeats), U(-1,1) actions, "
-                       "xi nominal+-10%%, fp64, %d threads, %.1f s" % (batch, steps, steps // reps, reps, cores, dt))
+                sample="%s: %d envs x %d env-steps (%d-step rollouts from reset states, %d repeats), U(-a,a) actions, "
+                       "xi nominal+-10%%, fp64, %d threads, %.1f s" % (env_id, batch, steps, steps // reps, reps, cores, dt))
 
 
 def main():
@@ -124,7 +133,7 @@ def main():
         achieved = bytes_step * B / (kavg_ms * 1e-3) / 1e9 if kavg_ms == kavg_ms else None
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass result (separate rocprofv3 --pmc runs)
-        if os.path.exists(tp):
+        if os.path.exists(tp) and args.env == ENV_ID:
             try:
                 traffic = json.load(open(tp)).get("bytes_per_launch")
             except Exception:
@@ -133,8 +142,8 @@ def main():
             "metric": METRIC, "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, batch %d per GPU, uniform DR over 4 link masses (nominal +-10%%), "
-                                   "U(-1,1) actions, auto-reset + xi resample" % (args.env, B),
+            "config": {"workload": "%s, batch %d per GPU, uniform DR over the %d-dim xi (nominal +-10%%), "
+                                   "U(-%.1f,%.1f) actions, auto-reset + xi resample" % (args.env, B, env.task_dim, amp, amp),
                        "global_batch": B * world, "parallelism": "index-sharded envs x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -144,7 +153,7 @@ def main():
             "solver_capped_waves": counters["solver_capped"], "nonfinite_lanes": counters["nonfinite"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, args.cpu_sample_steps)
+            out["cpu_baseline"] = cpu_baseline(args.env, B if args.env != "RandomHumanoid-v0" else 4096, args.cpu_sample_steps)
         print(json.dumps(out), flush=True)
     env.close()
     sharding.shutdown()

@@ -39,9 +39,13 @@ int mjo_env_init(mjoEnv* e, int kind, int variant) {
       if (variant) for (int b = 1; b <= 3; b++) e->model.body_mass[b] *= 0.8;   /* random_half_cheetah_unmodeled.py:28-31 */
       break;
     case MJO_ENV_HUMANOID:    /* random_humanoid.py:41 frame_skip 5; obs 376; xi = 13 masses + 17 dampings */
-      if (variant) return -1;
       mjo_build_humanoid(&e->model);
-      e->frame_skip = 5; e->obs_dim = 376; e->task_dim = 30; e->act_dim = 17; break;
+      e->frame_skip = 5; e->obs_dim = 376; e->task_dim = variant ? 23 : 30; e->act_dim = 17;
+      if (variant) {   /* random_humanoid_unmodeled.py:40-50 */
+        for (int b = 1; b <= 4; b++) e->model.body_mass[b] *= 0.8;
+        for (int d = 6; d <= 8; d++) e->model.dof_damping[d] *= 0.8;
+      }
+      break;
     default: return -1;
   }
   mjo_reset_data(&e->model, &e->data);
@@ -66,6 +70,10 @@ void mjo_env_get_task(const mjoEnv* e, double* xi) {
         for (int i = 0; i < 4; i++) xi[i] = m->body_mass[4 + i];
         for (int i = 0; i < 3; i++) xi[4 + i] = e->size[1 + i];
         xi[7] = m->pair_friction[0][0]; xi[8] = m->pair_friction[1][0]; break;
+      case MJO_ENV_HUMANOID:    /* random_humanoid_unmodeled.py:167-170 */
+        for (int i = 0; i < 9; i++) xi[i] = m->body_mass[5 + i];
+        for (int i = 0; i < 14; i++) xi[9 + i] = m->dof_damping[9 + i];
+        break;
     }
     return;
   }
@@ -104,6 +112,10 @@ void mjo_env_set_task(mjoEnv* e, const double* xi) {
         m->pair_friction[0][0] = xi[7]; m->pair_friction[0][1] = xi[7];
         m->pair_friction[1][0] = xi[8]; m->pair_friction[1][1] = xi[8];
         mjo_reset_data(m, &e->data);
+        break;
+      case MJO_ENV_HUMANOID:    /* random_humanoid_unmodeled.py:172-174 */
+        for (int i = 0; i < 9; i++) m->body_mass[5 + i] = xi[i];
+        for (int i = 0; i < 14; i++) m->dof_damping[9 + i] = xi[9 + i];
         break;
     }
     return;

@@ -527,8 +527,8 @@ static int fill_dims(int kind, int variant, rex_dims* d) {
     default: return -1;
   }
   if (rc == 0 && variant) {
-    if (variant != 1 || kind == REX_CARTPOLE || kind == REX_HUMANOID) return -1;   // RandomHumanoidUnmodeled-v0: not built yet
-    d->task_dim = kind == REX_HOPPER ? 3 : (kind == REX_HALFCHEETAH ? 5 : 9);
+    if (variant != 1 || kind == REX_CARTPOLE) return -1;
+    d->task_dim = kind == REX_HOPPER ? 3 : (kind == REX_HALFCHEETAH ? 5 : (kind == REX_WALKER2D ? 9 : 23));
   }
   return rc;
 }
@@ -536,7 +536,7 @@ static int fill_dims(int kind, int variant, rex_dims* d) {
 // (random_hopper_unmodeled.py:28-30, random_half_cheetah_unmodeled.py:33-36, random_walker2d_unmodeled.py:38-41)
 static int variant_task_dim(int kind, int variant, int full) {
   if (!variant) return full;
-  switch (kind) { case REX_HOPPER: return 3; case REX_HALFCHEETAH: return 5; case REX_WALKER2D: return 9; default: return -1; }
+  switch (kind) { case REX_HOPPER: return 3; case REX_HALFCHEETAH: return 5; case REX_WALKER2D: return 9; case REX_HUMANOID: return 23; default: return -1; }
 }
 static void variant_map(int kind, int variant, int full, int* map) {
   if (!variant) { for (int k = 0; k < full; k++) map[k] = k; return; }
@@ -544,6 +544,10 @@ static void variant_map(int kind, int variant, int full, int* map) {
     case REX_HOPPER: for (int k = 0; k < 3; k++) map[k] = 1 + k; break;                 // thigh, leg, foot masses
     case REX_HALFCHEETAH: for (int k = 0; k < 5; k++) map[k] = 3 + k; break;            // bfoot..ffoot masses, friction
     case REX_WALKER2D: { const int m[9] = {3, 4, 5, 6, 8, 9, 10, 11, 12}; for (int k = 0; k < 9; k++) map[k] = m[k]; break; }
+    case REX_HUMANOID:   // body_mass[5:] and dof_damping[9:] (random_humanoid_unmodeled.py:52-53,167-174)
+      for (int k = 0; k < 9; k++) map[k] = 4 + k;
+      for (int k = 0; k < 14; k++) map[9 + k] = 16 + k;
+      break;
   }
 }
 
@@ -650,6 +654,10 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hum), &mf, sizeof mf));
       for (int b = 0; b < 13; b++) h->nominal_xi[b] = (float)md.body_mass0[1 + b];          // random_humanoid.py:46
       for (int k = 0; k < 17; k++) h->nominal_xi[13 + k] = (float)md.dof_damping0[6 + k];   // :47
+      if (variant) {   // random_humanoid_unmodeled.py:40-50: masses 1..4 and dampings 6..8 frozen at 0.8x
+        for (int b = 0; b < 4; b++) h->nominal_xi[b] *= 0.8f;
+        for (int k = 0; k < 3; k++) h->nominal_xi[13 + k] *= 0.8f;
+      }
       HIP_TRY(hipMalloc(&d.aux, sizeof(float) * hum::NBODY * B));
       HIP_TRY(hipMemset(d.aux, 0, sizeof(float) * hum::NBODY * B));
       noise_var = 1e-3f;                                                                      // :39

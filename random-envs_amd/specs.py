@@ -101,8 +101,18 @@ WALKER2D_UNMODELED = EnvSpec(                         # random_envs/jinja/random
     reward_threshold=2200, preferred_lr=0.0005, noise_level=0.0,               # :51-52
     dr_on_reset=True)
 
+HUMANOID_UNMODELED = EnvSpec(                         # random_envs/jinja/random_humanoid_unmodeled.py
+    kind="humanoid",
+    names=["mass%d" % i for i in range(4, 13)] + ["damp%d" % i for i in range(4, 18)],      # :63-69
+    search_bounds=HUMANOID.search_bounds[4:13] + HUMANOID.search_bounds[16:],               # :88-120
+    lower_bounds=HUMANOID.lower_bounds[4:13] + HUMANOID.lower_bounds[16:],                  # :129-162
+    nominal_task=HUMANOID.nominal_task[4:13] + HUMANOID.nominal_task[16:],                  # :52-53
+    reward_threshold=2200, preferred_lr=0.0001, noise_level=0.0,                            # :71-72
+    dr_on_reset=True)
+
 SPECS = {"cartpole": CARTPOLE, "hopper": HOPPER, "halfcheetah": HALFCHEETAH, "walker2d": WALKER2D, "humanoid": HUMANOID}
-UNMODELED_SPECS = {"hopper": HOPPER_UNMODELED, "halfcheetah": HALFCHEETAH_UNMODELED, "walker2d": WALKER2D_UNMODELED}
+UNMODELED_SPECS = {"hopper": HOPPER_UNMODELED, "halfcheetah": HALFCHEETAH_UNMODELED, "walker2d": WALKER2D_UNMODELED,
+                   "humanoid": HUMANOID_UNMODELED}
 
 # gym ids registered by the reference: id -> (kind, kwargs)
 IDS = {
@@ -118,7 +128,8 @@ IDS = {
     "RandomHopperUnmodeled-v0": ("hopper", {"unmodeled": True}),             # random_hopper_unmodeled.py:146-150
     "RandomHalfCheetahUnmodeled-v0": ("halfcheetah", {"unmodeled": True}),   # random_half_cheetah_unmodeled.py:155-159
     "RandomWalker2dUnmodeled-v0": ("walker2d", {"unmodeled": True}),         # random_walker2d_unmodeled.py:187-191
+    "RandomHumanoidUnmodeled-v0": ("humanoid", {"unmodeled": True}),         # random_humanoid_unmodeled.py:275-279
 }
-# ids of the reference not built yet: creating them raises
-PENDING_IDS = ["RandomHumanoidUnmodeled-v0"]
+# ids of the reference not built yet: none (all 13 ids of SURVEY.md Appendix A are registered)
+PENDING_IDS = []
 MAX_EPISODE_STEPS = 500

@@ -42,7 +42,7 @@ def _soa(x, dim):
     return np.ascontiguousarray(x.T)
 
 
-UNMODELED_NX = {"hopper": 3, "halfcheetah": 5, "walker2d": 9}
+UNMODELED_NX = {"hopper": 3, "halfcheetah": 5, "walker2d": 9, "humanoid": 23}
 
 
 def oracle_batch_step(kind, qpos, qvel, action, xi, nthreads=8, tolerance=1e-12, variant=0):

@@ -100,3 +100,25 @@ def test_noisy_humanoid_only_noises_qpos_qvel(torch_mod):
     assert abs(diff[:, :45].std() - np.sqrt(1e-3)) < 2e-3            # sigma = sqrt(1e-3) (random_humanoid.py:39,193-204)
     assert np.abs(diff[:, 45:]).max() == 0
     clean.close(); noisy.close()
+
+
+def test_humanoid_unmodeled_id(torch_mod):
+    """RandomHumanoidUnmodeled-v0: masses 1..4 and dampings 6..8 frozen at 0.8x, 23-dim task
+    (random_humanoid_unmodeled.py:40-53)."""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_batch_step
+    torch = torch_mod
+    n = 256
+    env = rex.make("RandomHumanoidUnmodeled-v0", batch=n, autoreset=False)
+    assert env.task_dim == 23 and env.dyn_index_to_name(0) == "mass4" and env.dyn_index_to_name(22) == "damp17"
+    q, v, a, _ = _states(n, 5)
+    nom = np.array(env.original_task)
+    assert np.allclose(env.get_task().cpu().numpy(), nom[None], rtol=1e-6)
+    xi = (nom * np.random.RandomState(2).uniform(.8, 1.2, (n, 23))).astype(np.float32).astype(np.float64)
+    env.set_task(xi.astype(np.float32)); env.set_state(q, v)
+    obs, r, d, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+    ref = oracle_batch_step("humanoid", q, v, a, xi, variant=1, tolerance=0.0)
+    eo = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    assert np.percentile(eo, 99) < 2e-4, eo.max()
+    assert np.percentile(np.abs(r.cpu().numpy() - ref["reward"]), 99) < 2e-3
+    env.close()
