@@ -167,6 +167,48 @@ class VecRandomEnv(DRConfig):
         _native.check(self._L.rex_set_state(self._h, ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(v.data_ptr()), self._stream()))
         t.cuda.current_stream(self.device).synchronize()
 
+    # ---- state (de)serialisation helpers used by offline-replay callers (DROPO-style), SURVEY section 8 f2 ----
+    def get_sim_state(self):                  # random_hopper.py:151-152 (MjSimState -> (qpos, qvel) tensors)
+        q, v = self.get_state()
+        return q.clone(), v.clone()
+
+    def set_sim_state(self, mjstate):         # random_hopper.py:148-149
+        q, v = mjstate
+        return self.set_state(q, v)
+
+    def get_full_mjstate(self, state, template=None):
+        """Observation -> full (qpos, qvel) with the root x (and y for the humanoid) zeroed
+        (random_hopper.py:128-136, random_half_cheetah.py:136-146, random_walker2d.py:161-171,
+        random_humanoid.py:244-253).  `state` is [batch or n, obs_dim] (only its qpos/qvel part is read)."""
+        t = self._torch
+        st = t.as_tensor(state, dtype=t.float32, device=self.device).reshape(-1, self.dims.obs_dim)
+        nq, nv = self.dims.nq, self.dims.nv
+        if self.kind == "cartpole":
+            raise NotImplementedError("RandomCartPoleEnv has no get_full_mjstate (random_cartpole.py)")
+        skip = 2 if self.kind == "humanoid" else 1
+        q = t.zeros(st.shape[0], nq, dtype=t.float32, device=self.device)
+        q[:, skip:] = st[:, :nq - skip]
+        v = st[:, nq - skip:nq - skip + nv].clone()
+        return q, v
+
+    get_initial_mjstate = get_full_mjstate    # identical bodies upstream (random_hopper.py:138-146)
+
+    def replay_transitions(self, obs, action, xi=None):
+        """One logged transition per env under this env's (or the given) xi: set_sim_state(get_full_mjstate(obs)),
+        step(action) without auto-reset side effects -> next observation.  The massively parallel inner loop of
+        offline system identification (many candidate xi x one transition each)."""
+        keep = self.autoreset
+        self.autoreset = False; self._push_flags()
+        try:
+            if xi is not None:
+                self.set_task(xi)
+            q, v = self.get_full_mjstate(obs)
+            self.set_state(q, v)
+            nxt, r, d, _ = self.step(action)
+            return nxt.clone(), r.clone(), d.clone()
+        finally:
+            self.autoreset = keep; self._push_flags()
+
     def state_vector(self):                   # jinja_mujoco_env.py:231-235
         q, v = self.get_state()
         return self._torch.cat([q, v], 1)

@@ -1,0 +1,138 @@
+"""C-ABI / VecRandomEnv behaviour: ragged and tiny batches, masks, error paths, determinism,
+state helpers, the SB3-style adapter."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("batch", [1, 7, 100, 4097])
+def test_ragged_batches_match_full_lanes(torch_mod, batch):
+    """lane i of a ragged batch computes exactly what lane i of a big batch computes (global-index RNG,
+    no cross-lane coupling): covers the partial last wavefront."""
+    import random_envs_amd as rex
+    torch = torch_mod
+    big = rex.make("RandomHopper-v0", batch=8192, seed=7, autoreset=False)
+    small = rex.make("RandomHopper-v0", batch=batch, seed=7, autoreset=False)
+    for e in (big, small):
+        e.set_dr_distribution("uniform", [3.0, 4.0, 3.5, 4.5, 2.2, 3.2, 4.5, 5.5]); e.set_dr_training(True); e.reset()
+    a = torch.rand(8192, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    for _ in range(3):
+        ob, rb, db, _ = big.step(a); os_, rs, ds, _ = small.step(a[:batch])
+        assert torch.equal(ob[:batch], os_) and torch.equal(rb[:batch], rs) and torch.equal(db[:batch], ds)
+    big.close(); small.close()
+
+
+def test_error_paths(torch_mod):
+    import random_envs_amd as rex
+    from random_envs_amd import _native
+    L = _native.lib()
+    h = ctypes.c_void_p()
+    assert L.rex_create(99, 0, 16, 0, 0, 0, ctypes.byref(h)) == -1 and b"unknown env kind" in L.rex_last_error()
+    assert L.rex_create(1, 0, 0, 0, 0, 0, ctypes.byref(h)) == -1 and b"batch" in L.rex_last_error()
+    assert L.rex_create(0, 1, 16, 0, 0, 0, ctypes.byref(h)) == -1            # CartPole has no Unmodeled id
+    with pytest.raises(KeyError):
+        rex.make("RandomNope-v0")
+    env = rex.make("RandomHopper-v0", batch=8)
+    with pytest.raises(Exception, match="Unknown dr_type"):
+        env.set_dr_distribution("bogus", [])
+    with pytest.raises(ValueError):
+        env.set_random_task()                                                # random_env.py:201
+    fp = ctypes.POINTER(ctypes.c_float)
+    bad = (ctypes.c_float * 3)(1, 2, 3)
+    assert L.rex_set_dr(env._h, 1, ctypes.cast(bad, fp), 3, None) == -1 and b"expected 8 params" in L.rex_last_error()
+    assert L.rex_step(env._h, None, None, None, None, None, None, None) == -1
+    env.close()
+
+
+def test_masked_reset_and_random_task(torch_mod):
+    import random_envs_amd as rex
+    torch = torch_mod
+    B = 256
+    env = rex.make("RandomWalker2d-v0", batch=B, seed=3, autoreset=False)
+    nom = np.array(env.original_task)
+    env.set_dr_distribution("uniform", np.stack([0.9 * nom, 1.1 * nom], 1).ravel().tolist()); env.set_dr_training(True)
+    env.reset()
+    for _ in range(5):
+        env.step(torch.zeros(B, 6))
+    q0, v0 = [x.clone() for x in env.get_state()]; xi0 = env.get_task().clone()
+    mask = torch.zeros(B, dtype=torch.uint8); mask[::4] = 1
+    env.reset(mask)
+    q1, v1 = env.get_state(); xi1 = env.get_task()
+    m = mask.bool().cuda()
+    assert torch.equal(q1[~m], q0[~m]) and torch.equal(xi1[~m], xi0[~m])      # untouched lanes
+    assert (q1[m][:, 1] - 1.25).abs().max() <= 0.005 + 1e-6 and (xi1[m] != xi0[m]).any(1).all()
+    env.set_random_task(mask)                                                 # xi only, state untouched
+    q2, _ = env.get_state()
+    assert torch.equal(q2, q1) and (env.get_task()[m] != xi1[m]).any(1).all() and torch.equal(env.get_task()[~m], xi1[~m])
+    obs = torch.empty(17, B, device="cuda")
+    _native = __import__("random_envs_amd")._native
+    _native.check(_native.lib().rex_get_obs(env._h, ctypes.c_void_p(obs.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(obs.t(), torch.cat([q2[:, 1:], env.get_state()[1]], 1))
+    env.close()
+
+
+def test_seed_determinism_and_reseed(torch_mod):
+    import random_envs_amd as rex
+    def first_obs(seed, reseed=None):
+        env = rex.make("RandomHalfCheetah-v0", batch=64, seed=seed)
+        if reseed is not None:
+            assert env.seed(reseed) == [reseed]
+        o = env.reset().clone(); env.close(); return o
+    import torch
+    assert torch.equal(first_obs(1), first_obs(1)) and not torch.equal(first_obs(1), first_obs(2))
+    assert torch.equal(first_obs(1, reseed=2), first_obs(2))
+
+
+def test_state_helpers_and_replay(torch_mod):
+    """get_full_mjstate / replay_transitions: one logged transition x many candidate xi."""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_batch_step
+    torch = torch_mod
+    B = 512
+    env = rex.make("RandomHopper-v0", batch=B, seed=0, autoreset=False)
+    env.reset()
+    for _ in range(10):
+        env.step(torch.rand(B, 3) * 2 - 1)
+    obs = env.get_state(); q, v = obs
+    o = torch.cat([q[:, 1:], v], 1)
+    fq, fv = env.get_full_mjstate(o)
+    assert torch.equal(fq[:, 1:], q[:, 1:]) and (fq[:, 0] == 0).all() and torch.equal(fv, v)     # random_hopper.py:128-136
+    sq, sv = env.get_sim_state(); env.set_sim_state((sq, sv))
+    # the same transition (row 0) replayed under 512 different masses
+    nom = np.array(env.original_task)
+    xi = (nom * np.random.RandomState(0).uniform(.7, 1.3, (B, 4))).astype(np.float32)
+    a = torch.rand(1, 3) * 2 - 1
+    nxt, r, d = env.replay_transitions(o[:1].expand(B, -1), a.expand(B, -1), xi)
+    ref = oracle_batch_step("hopper", fq[:1].expand(B, -1).cpu().numpy().astype(np.float64), fv[:1].expand(B, -1).cpu().numpy().astype(np.float64),
+                            a.expand(B, -1).numpy().astype(np.float64), xi.astype(np.float64))
+    err = np.abs(nxt.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    assert np.percentile(err, 99) < 2e-4
+    assert nxt.std(0).max() > 1e-4          # different xi -> different next states
+    env.close()
+
+
+def test_sb3_style_adapter(torch_mod):
+    import random_envs_amd as rex
+    from random_envs_amd.sb3_adapter import SB3VecEnvAdapter
+    venv = SB3VecEnvAdapter(rex.make("RandomHopper-v0", batch=128, seed=0))
+    obs = venv.reset()
+    assert obs.shape == (128, 11) and obs.dtype == np.float32
+    seen = 0
+    for _ in range(60):
+        obs, rew, dones, infos = venv.step(np.random.uniform(-1, 1, (128, 3)).astype(np.float32))
+        for i in np.nonzero(dones)[0]:
+            assert infos[i]["terminal_observation"].shape == (11,) and "TimeLimit.truncated" in infos[i]
+            seen += 1
+    assert seen > 0 and venv.get_attr("task_dim") == [4]
+    venv.close()
