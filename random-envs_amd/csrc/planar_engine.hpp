@@ -481,8 +481,10 @@ enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4,
 template <class T, class S, bool SELF, int MAXIT = 24>
 REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
                                const Kin<T, S>& K, const Constraints<T, S>& C, const SelfRows<T, S>& R,
-                               const LaneParams<T, S>& P, T (&qacc)[S::NV]) {
-  static_for<0, S::NV>([&](auto II) { qacc[II] = qacc_smooth[II]; });
+                               const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, int ls_max) {
+  // MuJoCo starts at qacc_smooth (warmstart is disabled in all the XMLs); the minimiser is unique, so
+  // starting from the previous RK4 stage's solution only changes how fast the active set is found
+  static_for<0, S::NV>([&](auto II) { qacc[II] = warm ? qacc[II] : qacc_smooth[II]; });
   SolveStats st{0, false};
   // stop when the force residual |M a - f - J^T f_c| is at rounding level relative to the forces
   // that balance in it (the piecewise-quadratic cost makes Newton exact once the active set is right)
@@ -645,7 +647,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     T a = T(1), lo = T(0), hi = T(-1), d1, d2;
     deriv(a, d1, d2);
     bool ls_done = lane_done || abs_t(d1) <= d1ref;
-    for (int ls = 0; ls < 16; ++ls) {   // phi' is piecewise linear and increasing: safeguarded Newton
+    for (int ls = 0; ls < ls_max; ++ls) {   // phi' is piecewise linear and increasing: safeguarded Newton
       if (!REX_WAVE_ANY(!ls_done)) break;
       if (d1 < T(0)) lo = a; else hi = a;
       T an_ = a - d1 * rcp_t(d2);
@@ -685,7 +687,8 @@ extern __device__ unsigned long long g_ktime[8];
 // one forward-dynamics evaluation: qacc(q, v, ctrl)  ([3P] mj_forward)
 template <class T, class S>
 REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
-                          const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV]) {
+                          const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV],
+                          bool warm = false) {
   REX_STAMP(t_0);
   Kin<T, S> K;
   kinematics<T, S>(q, G, K);
@@ -725,10 +728,10 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   if (self_path) {   // rare: a capsule-capsule self contact may exist somewhere in this wave
     SelfRows<T, S> R;
     make_self_rows<T, S>(v, G, sp, K, R);
-    st = solve_newton<T, S, true>(M, f, a0, K, C, R, P, qacc);
+    st = solve_newton<T, S, true>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max);
   } else if (REX_WAVE_ANY(C.any)) {
     SelfRows<T, S> R; R.mask = 0u;
-    st = solve_newton<T, S, false>(M, f, a0, K, C, R, P, qacc);
+    st = solve_newton<T, S, false>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max);
   } else {
     static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
   }
@@ -744,18 +747,19 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
 // ([3P] mj_Euler).  Returns the OR of "solver hit its cap".
 template <class T, class S>
 REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
-                    const LaneParams<T, S>& P, const SolParams<T>& sp) {
+                    const LaneParams<T, S>& P, const SolParams<T>& sp, T (&acc)[S::NV], bool warm) {
+  // acc: in = qacc of the previous evaluation (solver warm start when `warm`), out = qacc of the last one
   const T h = T(S::TIMESTEP);
   T M[S::NV][S::NV];
   bool capped = false;
   if constexpr (S::RK4) {
     // stage loop kept rolled: one instance of forward() in the kernel, 4x smaller code and far
     // lower register pressure than four inlined copies
-    T q0[S::NV], v0[S::NV], dq[S::NV], dv[S::NV], acc[S::NV];
+    T q0[S::NV], v0[S::NV], dq[S::NV], dv[S::NV];
     static_for<0, S::NV>([&](auto II) { q0[II] = q[II]; v0[II] = v[II]; dq[II] = T(0); dv[II] = T(0); });
 #pragma unroll 1
     for (int stage = 0; stage < 4; ++stage) {
-      capped |= forward<T, S>(q, v, ctrl, G, P, sp, acc, M).capped;
+      capped |= forward<T, S>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0)).capped;
       const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3);   // B = [1/6 1/3 1/3 1/6]
       const T c = stage == 2 ? h : T(0.5) * h;                             // A = [.5; 0 .5; 0 0 1]
       static_for<0, S::NV>([&](auto II) { constexpr int i = II;
@@ -765,8 +769,8 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
         v[i] = stage == 3 ? v0[i] + h * dv[i] : vn; });
     }
   } else {
-    T acc[S::NV], rhs[S::NV];
-    capped |= forward<T, S>(q, v, ctrl, G, P, sp, acc, M).capped;
+    T rhs[S::NV];
+    capped |= forward<T, S>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm).capped;
     // (M + h*diag(damping)) a = qfrc_smooth + qfrc_constraint = M qacc
     sym_matvec<T, S>(M, acc, rhs);
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ; M[j + 2][j + 2] += h * G.damping[j]; });

@@ -206,6 +206,9 @@ REX_HD void derive_model(const T* size, PlanarGeom<T, S>& G, T (&nominal_mass)[S
   sp.lim_dmin = clampimp(d[4]); sp.lim_dmax = clampimp(d[5]); sp.lim_width = d[6];
   sp.con_K = T(1) / (sp.con_dmax * sp.con_dmax * tc * tc); sp.con_B = T(2) / (sp.con_dmax * tc);
   sp.lim_K = T(1) / (sp.lim_dmax * sp.lim_dmax * tc * tc); sp.lim_B = T(2) / (sp.lim_dmax * tc);
+  // measured on MI355X at B = 32768 (kernel ms, ls_max/warm): hopper 16/0 .247, 3/1 .205; walker2d .476 -> .386;
+  // half-cheetah (one evaluation per mj_step: the previous qacc is a poor guess) 16/0 .152, 3/0 .143, 3/1 .165
+  sp.ls_max = 3; sp.warm = S::RK4 ? 1 : 0;
 }
 
 // xi -> per-lane dynamic parameters (get_task/set_task scatter maps)

@@ -159,6 +159,8 @@ struct SolParams {
   // joint limits
   T lim_K, lim_B, lim_dmin, lim_dmax, lim_width;
   T meaninertia;   // scale of the convergence test
+  int ls_max;      // cap on extra line-search evaluations per Newton iteration (tuning knob)
+  int warm;        // start the solver from the previous evaluation's qacc (tuning knob)
 };
 
 }  // namespace rex

@@ -252,8 +252,10 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   const float x_before = q[0];
   q[0] = 0.0f;
   bool capped = false;
+  float acc[S::NV];
+  static_for<0, S::NV>([&](auto KK) { acc[KK] = 0.0f; });
 #pragma unroll 1
-  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S>(q, v, ctrl, G, P, sp);   // do_simulation, jinja_mujoco_env.py:170-173
+  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
 #if defined(REX_KTIME)
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[5], __builtin_amdgcn_s_memtime() - tk0);
 #endif
@@ -566,6 +568,7 @@ static void sp_to_float(const SolParams<double>& a, SolParams<float>& b) {
   b.con_K = (float)a.con_K; b.con_B = (float)a.con_B; b.con_dmin = (float)a.con_dmin; b.con_dmax = (float)a.con_dmax;
   b.con_width = (float)a.con_width; b.con_margin = (float)a.con_margin; b.lim_K = (float)a.lim_K; b.lim_B = (float)a.lim_B;
   b.lim_dmin = (float)a.lim_dmin; b.lim_dmax = (float)a.lim_dmax; b.lim_width = (float)a.lim_width; b.meaninertia = (float)a.meaninertia;
+  b.ls_max = a.ls_max; b.warm = a.warm;
 }
 
 template <class S>
@@ -665,6 +668,8 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   }
   h->flags.noise_std = sqrtf(noise_var);
   if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
+  if (getenv("REX_LS_MAX")) h->sp.ls_max = atoi(getenv("REX_LS_MAX"));   // tuning knobs
+  if (getenv("REX_WARM")) h->sp.warm = atoi(getenv("REX_WARM"));
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);

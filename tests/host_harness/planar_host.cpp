@@ -24,8 +24,9 @@ static void run_step(int n, int nsub, const double* qpos, const double* qvel, co
       derive_model<T, S>(s4, G, nominal, sp);
     }
     LaneParams<T, S> P; lane_params(S{}, x, P);
-    bool cap = false;
-    for (int s = 0; s < nsub; s++) cap |= substep<T, S>(q, v, c, G, P, sp);
+    bool cap = false; T acc[S::NV];
+    for (int k = 0; k < S::NV; k++) acc[k] = T(0);
+    for (int s = 0; s < nsub; s++) cap |= substep<T, S>(q, v, c, G, P, sp, acc, s > 0);
     for (int k = 0; k < S::NV; k++) { qpos_out[(size_t)k * n + i] = double(q[k]); qvel_out[(size_t)k * n + i] = double(v[k]); }
     if (capped) capped[i] = cap;
   }
