@@ -484,7 +484,9 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
                                const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, int ls_max) {
   // MuJoCo starts at qacc_smooth (warmstart is disabled in all the XMLs); the minimiser is unique, so
   // starting from the previous RK4 stage's solution only changes how fast the active set is found
-  static_for<0, S::NV>([&](auto II) { qacc[II] = warm ? qacc[II] : qacc_smooth[II]; });
+  // (a lane without any row is only here because another lane of its wave has one: it must leave with qacc_smooth)
+  const bool has_rows = C.any || (SELF && R.mask != 0u);
+  static_for<0, S::NV>([&](auto II) { qacc[II] = (warm && has_rows) ? qacc[II] : qacc_smooth[II]; });
   SolveStats st{0, false};
   // stop when the force residual |M a - f - J^T f_c| is at rounding level relative to the forces
   // that balance in it (the piecewise-quadratic cost makes Newton exact once the active set is right)
@@ -494,7 +496,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
   // every row kept its sign along the step (rows are linear in alpha), the cost was exactly
   // quadratic there and the step was its exact minimiser -> converged, independent of rounding
   unsigned p_lim = ~0u, p_e1 = ~0u, p_e2 = ~0u, p_e3 = ~0u, p_self = ~0u;
-  bool lane_done = !(C.any || (SELF && R.mask != 0u));
+  bool lane_done = !has_rows;
   constexpr int NC = 2 * S::NG;
   for (int it = 0; it < MAXIT; ++it) {
     if (!REX_WAVE_ANY(!lane_done)) break;
