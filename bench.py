@@ -75,11 +75,12 @@ def cpu_baseline(env_id, batch, steps, seed=0, min_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="envs per GPU")
     ap.add_argument("--env", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the per-launch HIP events")
     ap.add_argument("--cpu-sample-steps", type=int, default=8)
     args = ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
     for k in range(args.warmup):
         env.step_soa(actions[k % nact])
     sync()
-    env.enable_timing(True)
+    env.enable_timing(not args.no_kernel_timing)
     t0 = time.perf_counter()
     for k in range(args.steps):
         env.step_soa(actions[k % nact])

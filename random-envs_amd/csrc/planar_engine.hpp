@@ -311,21 +311,23 @@ REX_HD void capsule_pose(const Kin<T, S>& K, const PlanarGeom<T, S>& G, T (&p)[2
 }
 
 // closest points of two 2-D segments ([3P] mjc_CapsuleCapsule restated in the plane), then
-// circle-circle.  Returns up to two contacts in out[0..1].
+// circle-circle.  Up to two contacts (parallel axes), returned as scalars (no stack arrays).
+template <class T>
+struct Hit2 { T cx0, cz0, nx0, nz0, d0, cx1, cz1, nx1, nz1, d1; bool h0, h1; };
 template <class T>
 REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, const T (&p2)[2], const T (&a2)[2],
-                               T l2, T r2, T margin, T (&cx)[2], T (&cz)[2], T (&nx)[2], T (&nz)[2], T (&dist)[2],
-                               bool (&hit)[2]) {
-  hit[0] = hit[1] = false;
-  auto sphere = [&](T c1x, T c1z, T c2x, T c2z, int k) {
+                               T l2, T r2, T margin, Hit2<T>& H) {
+  H.h0 = H.h1 = false;
+  H.cx0 = H.cz0 = H.nx0 = H.nz0 = H.d0 = H.cx1 = H.cz1 = H.nx1 = H.nz1 = H.d1 = T(0);
+  auto sphere = [&](T c1x, T c1z, T c2x, T c2z) {   // fills slot 0, then slot 1
     T dx = c2x - c1x, dz = c2z - c1z;
     T len = sqrt_t(dx * dx + dz * dz), d = len - r1 - r2;
     if (d > margin) return;
     T ux = T(1), uz = T(0);
     if (len >= T(1e-15)) { ux = dx / len; uz = dz / len; }
     T px_ = c1x + ux * (r1 + d * T(0.5)), pz_ = c1z + uz * (r1 + d * T(0.5));
-    if (k == 0) { hit[0] = true; dist[0] = d; nx[0] = ux; nz[0] = uz; cx[0] = px_; cz[0] = pz_; }
-    else        { hit[1] = true; dist[1] = d; nx[1] = ux; nz[1] = uz; cx[1] = px_; cz[1] = pz_; }
+    if (!H.h0) { H.h0 = true; H.d0 = d; H.nx0 = ux; H.nz0 = uz; H.cx0 = px_; H.cz0 = pz_; }
+    else if (!H.h1) { H.h1 = true; H.d1 = d; H.nx1 = ux; H.nz1 = uz; H.cx1 = px_; H.cz1 = pz_; }
   };
   T difx = p1[0] - p2[0], difz = p1[1] - p2[1];
   T ma = a1[0] * a1[0] + a1[1] * a1[1], mb = -(a1[0] * a2[0] + a1[1] * a2[1]), mc = a2[0] * a2[0] + a2[1] * a2[1];
@@ -335,22 +337,21 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
     if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) / mc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) / mc; }
     if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) / ma; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) / ma; }
     if (x1 > l1) x1 = l1; else if (x1 < -l1) x1 = -l1;
-    sphere(p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, 0);
+    sphere(p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p2[0] + a2[0] * x2, p2[1] + a2[1] * x2);
     return;
   }
   // parallel axes: end points of segment 1 against segment 2, then of 2 against 1; first two hits
-  auto put = [&](T c1x, T c1z, T c2x, T c2z) { if (!hit[0]) sphere(c1x, c1z, c2x, c2z, 0); else if (!hit[1]) sphere(c1x, c1z, c2x, c2z, 1); };
   static_for<0, 2>([&](auto SS) {
     constexpr int sg = 2 * int(SS) - 1;
     T c1x = p1[0] + a1[0] * T(sg) * l1, c1z = p1[1] + a1[1] * T(sg) * l1;
     T x2 = (c1x - p2[0]) * a2[0] + (c1z - p2[1]) * a2[1];
-    if (x2 >= -l2 && x2 <= l2) put(c1x, c1z, p2[0] + a2[0] * x2, p2[1] + a2[1] * x2);
+    if (x2 >= -l2 && x2 <= l2) sphere(c1x, c1z, p2[0] + a2[0] * x2, p2[1] + a2[1] * x2);
   });
   static_for<0, 2>([&](auto SS) {
     constexpr int sg = 2 * int(SS) - 1;
     T c2x = p2[0] + a2[0] * T(sg) * l2, c2z = p2[1] + a2[1] * T(sg) * l2;
     T x1 = (c2x - p1[0]) * a1[0] + (c2z - p1[1]) * a1[1];
-    if (x1 >= -l1 && x1 <= l1) put(p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, c2x, c2z);
+    if (x1 >= -l1 && x1 <= l1) sphere(p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, c2x, c2z);
   });
 }
 
@@ -438,19 +439,20 @@ REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const
       constexpr int ba = S::geom_body[ga], bb = S::geom_body[gb];
       T p1[2], a1[2], p2[2], a2[2], l1, l2;
       capsule_pose<T, S, ga>(K, G, p1, a1, l1); capsule_pose<T, S, gb>(K, G, p2, a2, l2);
-      T cx[2], cz[2], nx[2], nz[2], dist[2]; bool hit[2];
-      capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, cx, cz, nx, nz, dist, hit);
+      Hit2<T> H;
+      capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, H);
       static_for<0, 2>([&](auto KK) {
         constexpr int k = KK; constexpr int r = 2 * p + k;
-        bool act = hit[k] && dist[k] < sp.con_margin;
+        const bool hit_k = k == 0 ? H.h0 : H.h1; const T dist_k = k == 0 ? H.d0 : H.d1;
+        bool act = hit_k && dist_k < sp.con_margin;
         if (act) {
           mask |= 1u << r;
-          R.px[r] = cx[k]; R.pz[r] = cz[k]; R.nx[r] = nx[k]; R.nz[r] = nz[k];
-          T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist[k] - sp.con_margin));
+          R.px[r] = k == 0 ? H.cx0 : H.cx1; R.pz[r] = k == 0 ? H.cz0 : H.cz1; R.nx[r] = k == 0 ? H.nx0 : H.nx1; R.nz[r] = k == 0 ? H.nz0 : H.nz1;
+          T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist_k - sp.con_margin));
           R.D[r] = imp / max_t(T(1e-15), (T(1) - imp) * (G.tran_invw[ba] + G.tran_invw[bb]));
           T ta, na, tb, nb; jdot<T, S, ba>(K, R.px[r], R.pz[r], v, ta, na); jdot<T, S, bb>(K, R.px[r], R.pz[r], v, tb, nb);
           T vel = R.nx[r] * (tb - ta) + R.nz[r] * (nb - na);
-          R.aref[r] = -sp.con_B * vel - sp.con_K * imp * (dist[k] - sp.con_margin);
+          R.aref[r] = -sp.con_B * vel - sp.con_K * imp * (dist_k - sp.con_margin);
         } else { R.px[r] = R.pz[r] = R.nx[r] = R.nz[r] = R.D[r] = R.aref[r] = T(0); }
       });
     });

@@ -70,7 +70,7 @@ struct DRParams {
   float lo[MAX_XI], hi[MAX_XI];   // fullgaussian: search bounds for denormalisation
   int map[MAX_XI];          // task index -> row of the kernels' full xi block (identity for the regular ids;
                             // the Unmodeled ids randomise a suffix only)
-  float chol[MAX_XI * MAX_XI];    // fullgaussian: lower Cholesky factor of cov, row-major
+  const float* chol;        // fullgaussian: lower Cholesky factor of cov, row-major [dim][MAX_XI], DEVICE memory
 };
 
 constexpr unsigned long long EP_STRIDE = 1ull << 16;   // Philox offsets per episode
@@ -84,36 +84,39 @@ __device__ __forceinline__ float truncnorm2(float u) {
   return fminf(fmaxf(x, -2.0f), 2.0f);
 }
 
-// RandomEnv.sample_task (random_env.py:148-203), one lane = one env.  Cold path (reset only):
-// runtime dimension, rolled loops.
-__device__ void sample_task(const DRParams& dr, rocrand_state_philox4x32_10* st, float* xi, unsigned long long* counters) {
+// RandomEnv.sample_task (random_env.py:148-203), one lane = one env.  Cold path (reset only): runtime dimension,
+// rolled loops, every draw stored straight to its xi row (no per-lane array => the kernel needs no scratch).
+__device__ void sample_task(const DRParams& dr, unsigned long long seed, unsigned long long subseq, unsigned long long offset,
+                            float* __restrict__ xi_rows, size_t B, unsigned i, unsigned long long* counters) {
   const int d = dr.dim;
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(seed, subseq, offset, &st);
   if (dr.type == REX_DR_UNIFORM) {           // :150-151  U(min, max) per dim
-    for (int k = 0; k < d; k++) { float u = rocrand_uniform(st); xi[k] = dr.a[k] + (dr.b[k] - dr.a[k]) * (1.0f - u); }
+    for (int k = 0; k < d; k++) { float u = rocrand_uniform(&st); (xi_rows + (size_t)dr.map[k] * B)[i] = dr.a[k] + (dr.b[k] - dr.a[k]) * (1.0f - u); }
   } else if (dr.type == REX_DR_TRUNCNORM) {  // :153-171 (intended semantics; the reference raises NameError)
     for (int k = 0; k < d; k++) {
       float lb = dr.lower[k];
-      float obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(st));
+      float obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(&st));
       // `attempts` 1,2 keep a redraw; the third redraw is overwritten by lower_bound (:162-167)
-      for (int att = 0; att < 2 && obs < lb; att++) obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(st));
+      for (int att = 0; att < 2 && obs < lb; att++) obs = dr.a[k] + dr.b[k] * truncnorm2(rocrand_uniform(&st));
       if (obs < lb) obs = lb;
-      xi[k] = obs;
+      (xi_rows + (size_t)dr.map[k] * B)[i] = obs;
     }
   } else if (dr.type == REX_DR_GAUSSIAN) {   // :173-190: redraw while < 0.1, raise after the 3rd failure
     for (int k = 0; k < d; k++) {
-      float obs = dr.a[k] + dr.b[k] * rocrand_normal(st);
-      for (int att = 0; att < 2 && obs < 0.1f; att++) obs = dr.a[k] + dr.b[k] * rocrand_normal(st);
+      float obs = dr.a[k] + dr.b[k] * rocrand_normal(&st);
+      for (int att = 0; att < 2 && obs < 0.1f; att++) obs = dr.a[k] + dr.b[k] * rocrand_normal(&st);
       if (obs < 0.1f) { obs = 0.1f; atomicAdd(counters + 1, 1ull); }   // a device lane cannot raise: clamp + count
-      xi[k] = obs;
+      (xi_rows + (size_t)dr.map[k] * B)[i] = obs;
     }
   } else if (dr.type == REX_DR_FULLGAUSSIAN) {  // :192-198: MVN in normalised [0,4]^d, clip, denormalise (:205-220)
-    float z[MAX_XI];
-    for (int k = 0; k < d; k++) z[k] = rocrand_normal(st);
+    // x_k = mean_k + sum_{j<=k} L_kj z_j: the z stream is replayed from the counter for every k (no z[] array)
     for (int k = 0; k < d; k++) {
-      float s = dr.a[k];
-      for (int j = 0; j <= k; j++) s += dr.chol[k * MAX_XI + j] * z[j];
-      s = fminf(fmaxf(s, 0.0f), 4.0f);
-      xi[k] = s * (dr.hi[k] - dr.lo[k]) * 0.25f + dr.lo[k];
+      rocrand_state_philox4x32_10 sz; rocrand_init(seed, subseq, offset, &sz);
+      float acc = dr.a[k];
+      for (int j = 0; j <= k; j++) acc += dr.chol[k * MAX_XI + j] * rocrand_normal(&sz);
+      acc = fminf(fmaxf(acc, 0.0f), 4.0f);
+      (xi_rows + (size_t)dr.map[k] * B)[i] = acc * (dr.hi[k] - dr.lo[k]) * 0.25f + dr.lo[k];
     }
   }
 }
@@ -192,8 +195,7 @@ __global__ void __launch_bounds__(64) cartpole_reset_kernel(DevState s, DRParams
     if (obs) { obs[i] = v[0]; obs[B + i] = v[1]; obs[2 * B + i] = v[2]; obs[3 * B + i] = v[3]; }
   }
   if (resample && dr.type != REX_DR_NONE) {
-    float xi[MAX_XI]; sample_task(dr, &st, xi, s.counters);
-    for (int k = 0; k < dr.dim; k++) s.xi[(size_t)dr.map[k] * B + i] = xi[k];
+    sample_task(dr, s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, s.xi, (size_t)B, i, s.counters);
   }
 }
 
@@ -234,7 +236,8 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
                                                          SolParams<float> sp, const float* __restrict__ action,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          unsigned char* __restrict__ done_out,
-                                                         unsigned char* __restrict__ trunc_out, float* __restrict__ term_obs) {
+                                                         unsigned char* __restrict__ trunc_out, float* __restrict__ term_obs,
+                                                         DRParams dr, int fused_reset, int resample) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
@@ -294,22 +297,21 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; (term_obs + (size_t)k * B)[i] = (obs + (size_t)k * B)[i]; });
   reward[i] = r; done_out[i] = d ? 1 : 0;
   if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+  // auto-reset fused into the step launch: finished lanes restart here (saves the masked reset launch and
+  // the kernel boundary, ~10 % of a hopper step at B = 32768)
+  if (fused_reset && d) planar_reset_lane<S>(s, fl, dr, resample, 1, i, obs);
 }
 
 // reset_model (random_hopper.py:112-120, random_half_cheetah.py:123-131, random_walker2d.py:144-153)
-// + set_random_task (random_env.py:37-39) for the masked lanes.
+// + set_random_task (random_env.py:37-39) for one lane.
 template <class S>
-__global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
-                                                          const unsigned char* __restrict__ mask, int mask_bit,
-                                                          float* __restrict__ obs) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
-  if (i >= s.B) return;
-  if (mask && !(mask[i] & mask_bit)) return;
+__device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepFlags& fl, const DRParams& dr, int resample,
+                                                  int reset_state, unsigned i, float* __restrict__ obs) {
   const long long B = s.B;
   unsigned ep = s.episode[i] + 1; s.episode[i] = ep;
-  rocrand_state_philox4x32_10 st;
-  rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
   if (reset_state) {
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
     float q[S::NV], v[S::NV];
     const float c = S::INIT_NOISE;
     static_for<0, S::NV>([&](auto KK) { constexpr int k = KK;
@@ -327,11 +329,19 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
     }
   }
   if (resample && dr.type != REX_DR_NONE) {
-    rocrand_state_philox4x32_10 st3;   // separate stream region so the xi draw does not depend on reset_state
-    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, &st3);
-    float xi[MAX_XI]; sample_task(dr, &st3, xi, s.counters);
-    for (int k = 0; k < dr.dim; k++) (s.xi + (size_t)dr.map[k] * B)[i] = xi[k];
+    // separate stream region so the xi draw does not depend on reset_state
+    sample_task(dr, s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, s.xi, (size_t)B, i, s.counters);
   }
+}
+
+template <class S>
+__global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
+                                                          const unsigned char* __restrict__ mask, int mask_bit,
+                                                          float* __restrict__ obs) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.B) return;
+  if (mask && !(mask[i] & mask_bit)) return;
+  planar_reset_lane<S>(s, fl, dr, resample, reset_state, i, obs);
 }
 
 // walker2d: re-derive the per-env model constants from the xi lengths for the masked lanes
@@ -463,10 +473,7 @@ __global__ void __launch_bounds__(64) humanoid_reset_kernel(DevState s, StepFlag
     s.t[i] = 0; s.done[i] = 0;
   }
   if (resample && dr.type != REX_DR_NONE) {
-    rocrand_state_philox4x32_10 st3;
-    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, &st3);
-    float xi[MAX_XI]; sample_task(dr, &st3, xi, s.counters);
-    for (int k = 0; k < dr.dim; k++) (s.xi + (size_t)dr.map[k] * B)[i] = xi[k];
+    sample_task(dr, s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, s.xi, B, i, s.counters);
   }
 }
 
@@ -505,6 +512,7 @@ struct rex_env {
   float nominal_xi[MAX_XI] = {0};   // FULL xi block of the kernels
   int full_dim = 0;                 // rows of the full xi block (dims.task_dim = rows exposed as the task)
   float* d_scratch = nullptr;   // MAX_XI floats
+  float* d_chol = nullptr;      // MAX_XI*MAX_XI floats (fullgaussian Cholesky factor)
   // timing
   int timing = 0;
   std::vector<hipEvent_t> ev0, ev1;
@@ -626,6 +634,9 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   HIP_TRY(hipMalloc(&d.done, B));
   HIP_TRY(hipMalloc(&d.counters, sizeof(unsigned long long) * 4));
   HIP_TRY(hipMalloc(&h->d_scratch, sizeof(float) * MAX_XI));
+  HIP_TRY(hipMalloc(&h->d_chol, sizeof(float) * MAX_XI * MAX_XI));
+  HIP_TRY(hipMemset(h->d_chol, 0, sizeof(float) * MAX_XI * MAX_XI));
+  h->dr.chol = h->d_chol;
   HIP_TRY(hipMemset(d.qpos, 0, sizeof(float) * dims.nq * B));
   HIP_TRY(hipMemset(d.qvel, 0, sizeof(float) * dims.nv * B));
   HIP_TRY(hipMemset(d.t, 0, sizeof(int) * B));
@@ -701,7 +712,7 @@ extern "C" int rex_destroy(rex_t* h) {
   hipSetDevice(h->device);
   hipDeviceSynchronize();
   hipFree(h->dev.qpos); hipFree(h->dev.qvel); hipFree(h->dev.xi); hipFree(h->dev.t); hipFree(h->dev.episode);
-  hipFree(h->dev.done); hipFree(h->dev.counters); hipFree(h->d_scratch);
+  hipFree(h->dev.done); hipFree(h->dev.counters); hipFree(h->d_scratch); hipFree(h->d_chol);
   if (h->dev.geom) hipFree(h->dev.geom);
   if (h->dev.aux) hipFree(h->dev.aux);
   for (auto e : h->ev0) hipEventDestroy(e);
@@ -722,7 +733,10 @@ extern "C" int rex_set_dr(rex_t* h, int dr_type, const float* params, int n_para
     case REX_DR_FULLGAUSSIAN:
       if (!params || n_params != d + d * d + 2 * d) return set_err(REX_ERR_ARG, "set_dr(fullgaussian): expected %d params, got %d", 3 * d + d * d, n_params);
       for (int i = 0; i < d; i++) dr.a[i] = params[i];
-      for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) dr.chol[i * MAX_XI + j] = params[d + i * d + j];
+      { static thread_local float hc[MAX_XI * MAX_XI]; memset(hc, 0, sizeof hc);
+        for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) hc[i * MAX_XI + j] = params[d + i * d + j];
+        HIP_TRY(hipSetDevice(h->device)); HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h->d_chol, hc, sizeof hc, hipMemcpyHostToDevice)); }
       for (int i = 0; i < d; i++) { dr.lo[i] = params[d + d * d + i]; dr.hi[i] = params[2 * d + d * d + i]; }
       break;
     case REX_DR_NONE: break;
@@ -781,6 +795,10 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   if (!action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_step: null buffer");
   hipStream_t st = (hipStream_t)stream;
   const dim3 g(grid_for(h->B)), b(lanes_for(h->B));
+  const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
+  // planar envs reset finished lanes inside the step kernel; walker2d with DR needs the separate derive launch
+  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH ||
+                                      (h->kind == REX_WALKER2D && !(resample_on_reset && h->dr.type != REX_DR_NONE)))) ? 1 : 0;
   if (h->timing) {
     if (h->ev_n >= h->ev0.size()) {
       hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
@@ -791,21 +809,18 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
     case REX_CARTPOLE:
       hipLaunchKernelGGL(cartpole_step_kernel, g, b, 0, st, h->dev, h->flags, (const int*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
     case REX_HOPPER:
-      hipLaunchKernelGGL(planar_step_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->g_hopper, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+      hipLaunchKernelGGL(planar_step_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->g_hopper, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
     case REX_HALFCHEETAH:
-      hipLaunchKernelGGL(planar_step_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->g_cheetah, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+      hipLaunchKernelGGL(planar_step_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->g_cheetah, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
     case REX_WALKER2D:
-      hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+      hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
     case REX_HUMANOID:
       hipLaunchKernelGGL(humanoid_step_kernel, g, b, 0, st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
   }
   if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
   HIP_TRY(hipGetLastError());
   h->step_count += h->B;
-  if (h->autoreset) {
-    int resample = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
-    return do_reset(h, h->dev.done, 2, resample, 1, obs_out, st);
-  }
+  if (h->autoreset && !fused) return do_reset(h, h->dev.done, 2, resample_on_reset, 1, obs_out, st);
   return REX_OK;
 }
 
