@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--env", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the per-launch HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the launch path on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--cpu-sample-steps", type=int, default=8)
     args = ap.parse_args()
 
@@ -88,10 +90,12 @@ def main():
     import __graft_entry__ as graft
     from random_envs_amd import sharding
     rank, local_rank, world = sharding.dist_env()
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if rank == 0:
         graft.build()
-    sharding.init("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; no-op at N=1
+    sharding.init(args.backend, torch.device("cuda", local_rank))   # "nccl" = RCCL over xGMI; no-op at N=1
     sharding.barrier()
     import random_envs_amd as rex
 
@@ -124,7 +128,8 @@ def main():
     env.enable_timing(False)
 
     # the only collectives of the path: SUM of the step counter, MAX of the elapsed time
-    total_steps, elapsed = sharding.reduce_counter_and_time(args.steps * B, elapsed, torch.device("cuda", local_rank))
+    total_steps, elapsed = sharding.reduce_counter_and_time(args.steps * B, elapsed,
+                                                            torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu"))
     counters = env.counters()
 
     if rank == 0:

@@ -22,7 +22,9 @@
 namespace rex {
 
 REX_HD void sincos_t(float a, float& s, float& c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(REX_FAST_SINCOS)
+  s = __sinf(a); c = __cosf(a);
+#elif defined(__HIP_DEVICE_COMPILE__)
   sincosf(a, &s, &c);
 #else
   s = sinf(a); c = cosf(a);
