@@ -8,7 +8,7 @@ TAG=${1:-run}
 P=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $P
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline > $P/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py --no-cpu-baseline > $P/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $P/bench_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $P/bench_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_sq -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $P/bench_pmc_sq.log 2>&1
