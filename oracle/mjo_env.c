@@ -361,3 +361,39 @@ int mjo_probe_contacts(int kind, const double* qpos, const double* qvel, const d
   free(e);
   return n;
 }
+
+/* world-frame dump of a compiled model at qpos0 (tests compare it with tests/golden/mjcf_tables.json):
+ * jnt rows: type, anchor(3), axis(3), limited, lo, hi, armature, damping, stiffness, qpos0  (14)
+ * geom rows: type, p0(3), p1(3), radius, friction0, condim, margin, body                   (12)
+ * act rows: joint, gear, lo, hi (4);  opt: timestep, integrator, solver, iterations, gravity_z (5) */
+int mjo_model_dump(int kind, const double* size, double* jnt, double* geom, double* act, double* opt, int* dims) {
+  mjoModel* m = (mjoModel*)malloc(sizeof(mjoModel)); mjoData* d = (mjoData*)malloc(sizeof(mjoData));
+  switch (kind) {
+    case MJO_ENV_HOPPER: mjo_build_hopper(m, size); break;
+    case MJO_ENV_WALKER2D: mjo_build_walker2d(m, size); break;
+    case MJO_ENV_HALFCHEETAH: mjo_build_halfcheetah(m, size); break;
+    case MJO_ENV_HUMANOID: mjo_build_humanoid(m); break;
+    default: free(m); free(d); return -1;
+  }
+  mjo_reset_data(m, d); mjo_forward(m, d);
+  for (int j = 0; j < m->njnt; j++) {
+    double* r = jnt + 14 * j; int da = m->jnt_dofadr[j] + (m->jnt_type[j] == MJO_JNT_FREE ? 3 : 0);
+    r[0] = m->jnt_type[j];
+    for (int k = 0; k < 3; k++) { r[1 + k] = d->dof_anchor[da][k]; r[4 + k] = m->jnt_type[j] == MJO_JNT_FREE ? 0 : d->dof_axis[da][k]; }
+    r[7] = m->jnt_limited[j]; r[8] = m->jnt_range[j][0]; r[9] = m->jnt_range[j][1];
+    r[10] = m->dof_armature[m->jnt_dofadr[j]]; r[11] = m->dof_damping[m->jnt_dofadr[j]]; r[12] = m->jnt_stiffness[j];
+    r[13] = m->qpos0[m->jnt_qposadr[j]];
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    double* r = geom + 12 * g; const double* X = d->geom_xmat[g]; double ax[3] = {X[2], X[5], X[8]}, h = m->geom_size[g][1];
+    r[0] = m->geom_type[g];
+    for (int k = 0; k < 3; k++) { double hh = m->geom_type[g] == MJO_GEOM_CAPSULE ? h : 0; r[1 + k] = d->geom_xpos[g][k] + ax[k] * hh; r[4 + k] = d->geom_xpos[g][k] - ax[k] * hh; }
+    r[7] = m->geom_size[g][0]; r[8] = m->geom_friction[g][0]; r[9] = m->geom_condim[g]; r[10] = m->geom_margin[g]; r[11] = m->geom_body[g];
+  }
+  for (int u = 0; u < m->nu; u++) { double* r = act + 4 * u; r[0] = m->dof_jnt[m->act_dof[u]]; r[1] = m->act_gear[u]; r[2] = m->act_ctrlrange[u][0]; r[3] = m->act_ctrlrange[u][1]; }
+  opt[0] = m->timestep; opt[1] = m->integrator; opt[2] = m->solver; opt[3] = m->iterations; opt[4] = m->gravity[2];
+  dims[0] = m->nbody; dims[1] = m->njnt; dims[2] = m->ngeom; dims[3] = m->nu; dims[4] = m->npair;
+  for (int p = 0; p < m->npair && p < 8; p++) { opt[5 + 3 * p] = m->pair_explicit[p]; opt[6 + 3 * p] = m->pair_friction[p][0]; opt[7 + 3 * p] = m->pair_dim[p]; }
+  free(m); free(d);
+  return 0;
+}
