@@ -211,6 +211,54 @@ REX_HD void derive_model(const T* size, PlanarGeom<T, S>& G, T (&nominal_mass)[S
   sp.ls_max = 3; sp.warm = S::RK4 ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Walker2d per-env geometry, compact form.  Of the 105 floats of PlanarGeom only 25 distinct values depend
+// on the xi lengths (both legs are built from the same formulas, x offsets are zero except the feet, radii /
+// armature / damping / stiffness are constants): the per-env SoA block stores those 25, the step kernel expands
+// them over a uniform nominal PlanarGeom.  kWalkerSlot[f] = compact slot of flat field f, or -1 (uniform).
+// tests/test_planar_engine_host.py checks the table against derive_model() for random lengths.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kWalkerCompact = 25;
+struct WalkerMap {
+  int slot[105];
+  constexpr WalkerMap() : slot() {
+    for (int f = 0; f < 105; f++) slot[f] = -1;
+    constexpr int JA = 0, CO = 14, IYY = 28, E1 = 35, E2 = 49, TR = 70, DW = 77;   // field bases (floats)
+    for (int side = 0; side < 2; side++) {
+      const int b = 1 + 3 * side;
+      slot[JA + 2 * b + 1] = 0; slot[JA + 2 * (b + 1) + 1] = 1; slot[JA + 2 * (b + 2) + 1] = 2;       // anchors (z)
+      slot[CO + 2 * b + 1] = 4; slot[CO + 2 * (b + 1) + 1] = 5; slot[CO + 2 * (b + 2) + 0] = 6;       // COM offsets
+      slot[IYY + b] = 8; slot[IYY + b + 1] = 9; slot[IYY + b + 2] = 10;
+      slot[E2 + 2 * b + 1] = 13;                                                                      // thigh lower end z
+      slot[E2 + 2 * (b + 1) + 1] = 14;                                                                // leg lower end z
+      slot[E2 + 2 * (b + 2) + 0] = 15;                                                                // foot far end x
+      slot[TR + b] = 17; slot[TR + b + 1] = 18; slot[TR + b + 2] = 19;
+      slot[DW + b] = 20; slot[DW + b + 1] = 21; slot[DW + b + 2] = 22;
+    }
+    slot[CO + 1] = 3;            // torso COM z
+    slot[IYY + 0] = 7;
+    slot[E1 + 1] = 11; slot[E2 + 1] = 12;   // torso capsule ends z
+    slot[TR + 0] = 16;
+    // slots 23, 24 spare
+  }
+};
+constexpr WalkerMap kWalkerMap{};
+
+template <class T>
+REX_HD void walker_compact_from_geom(const PlanarGeom<T, Walker2dSpec>& G, T* c) {
+  const T* flat = reinterpret_cast<const T*>(&G);
+  for (int k = 0; k < kWalkerCompact; k++) c[k] = T(0);
+  for (int f = 0; f < 105; f++) if (kWalkerMap.slot[f] >= 0) c[kWalkerMap.slot[f]] = flat[f];
+}
+template <class T, class Load>
+REX_HD void walker_expand(const PlanarGeom<T, Walker2dSpec>& uniform, Load&& load, PlanarGeom<T, Walker2dSpec>& G) {
+  G = uniform;
+  T c[kWalkerCompact];
+  static_for<0, 23>([&](auto KK) { constexpr int k = KK; c[k] = load(k); });
+  T* flat = reinterpret_cast<T*>(&G);
+  static_for<0, 105>([&](auto FF) { constexpr int f = FF; if constexpr (kWalkerMap.slot[f] >= 0) flat[f] = c[kWalkerMap.slot[f]]; });
+}
+
 // xi -> per-lane dynamic parameters (get_task/set_task scatter maps)
 template <class T>
 REX_HD void lane_params(const HopperSpec&, const T* xi, LaneParams<T, HopperSpec>& P) {

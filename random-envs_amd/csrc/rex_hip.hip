@@ -207,11 +207,8 @@ template <class S> constexpr int geom_floats() { return sizeof(PlanarGeom<float,
 template <class S>
 __device__ __forceinline__ void load_geom(const DevState& s, unsigned i, const PlanarGeom<float, S>& uniform,
                                           PlanarGeom<float, S>& G) {
-  if constexpr (S::KIND == 3) {   // walker2d: geometry is a function of the xi lengths
-    float* dst = reinterpret_cast<float*>(&G);
-    constexpr int N = geom_floats<S>();
-#pragma unroll
-    for (int k = 0; k < N; k++) dst[k] = (s.geom + (size_t)k * s.B)[i];
+  if constexpr (S::KIND == 3) {   // walker2d: geometry is a function of the xi lengths (25 distinct values per env)
+    walker_expand(uniform, [&](int k) { return (s.geom + (size_t)k * s.B)[i]; }, G);
   } else {
     G = uniform;
   }
@@ -356,9 +353,9 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
   for (int k = 0; k < 4; k++) size[k] = (double)s.xi[(long long)(7 + k) * s.B + i];
   PlanarGeom<double, S> G; SolParams<double> sp; double nominal[S::NB];
   derive_model<double, S>(size, G, nominal, sp);
-  const double* src = reinterpret_cast<const double*>(&G);
-  constexpr int N = geom_floats<S>();
-  for (int k = 0; k < N; k++) (s.geom + (size_t)k * s.B)[i] = (float)src[k];
+  double c[kWalkerCompact];
+  walker_compact_from_geom(G, c);
+  for (int k = 0; k < kWalkerCompact; k++) (s.geom + (size_t)k * s.B)[i] = (float)c[k];
   // RandomWalker2dUnmodeled.set_task rebuilds the model and rewrites body_mass[4:] only, so the frozen
   // masses 1..3 become the geometry-derived ones of the new lengths (random_walker2d_unmodeled.py:109-116)
   if (refresh_frozen_masses) for (int b = 0; b < 3; b++) (s.xi + (size_t)b * s.B)[i] = (float)nominal[b];
@@ -660,7 +657,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       if (variant) for (int b = 0; b < 3; b++) h->nominal_xi[b] *= 0.8f;                                                 // :33-36 (until the first set_task, Q6)
       for (int k = 0; k < 4; k++) h->nominal_xi[7 + k] = (float)wsize[k];                                                // random_walker2d.py:21
       h->nominal_xi[11] = 0.9f; h->nominal_xi[12] = 1.9f;                                                                // random_walker2d.py:37
-      HIP_TRY(hipMalloc(&d.geom, sizeof(float) * geom_floats<Walker2dSpec>() * B));
+      HIP_TRY(hipMalloc(&d.geom, sizeof(float) * kWalkerCompact * B));
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
     case REX_HUMANOID: {
       static hum::Model<double> md; static hum::Model<float> mf; static bool built = false;

@@ -84,3 +84,18 @@ int ph_constants(int kind, int f32, const double* size, double* mass, double* iy
   return 0;
 }
 }
+
+// walker compact-geometry table check: expand(compact(derive(size))) must reproduce derive(size) field by field
+extern "C" int ph_walker_compact_check(const double* size, const double* nominal_size, double* max_err) {
+  using S = Walker2dSpec;
+  PlanarGeom<double, S> G, U, E; SolParams<double> sp; double nominal[S::NB];
+  double s1[4] = {size[0], size[1], size[2], size[3]}, s0[4] = {nominal_size[0], nominal_size[1], nominal_size[2], nominal_size[3]};
+  derive_model<double, S>(s1, G, nominal, sp); derive_model<double, S>(s0, U, nominal, sp);
+  double c[kWalkerCompact]; walker_compact_from_geom(G, c);
+  walker_expand(U, [&](int k) { return c[k]; }, E);
+  const double* a = reinterpret_cast<const double*>(&G); const double* b = reinterpret_cast<const double*>(&E);
+  double e = 0; int worst = -1;
+  for (int f = 0; f < 105; f++) { double d = fabs(a[f] - b[f]); if (d > e) { e = d; worst = f; } }
+  *max_err = e;
+  return worst;
+}

@@ -83,3 +83,17 @@ def test_hopper_self_collision_rows():
         qa, _, _ = host_forward("hopper", False, q, v, a, xi)
         assert np.abs(qa - o["qacc"]).max() / (1 + np.abs(o["qacc"]).max()) < 1e-7
     assert hits > 20
+
+
+def test_walker_compact_geometry_table():
+    """the 25-slot compact per-env geometry (planar_model.hpp kWalkerMap) expands back to all 105 PlanarGeom
+    fields for arbitrary xi lengths"""
+    import ctypes
+    from host_harness.build import lib as hlib
+    L = hlib(); D = ctypes.POINTER(ctypes.c_double)
+    rng = np.random.RandomState(0); nom = np.array([.4, .45, .6, .2])
+    for _ in range(50):
+        size = np.array([rng.uniform(.15, 1), rng.uniform(.15, 1), rng.uniform(.15, 1), rng.uniform(.15, 1)])
+        err = ctypes.c_double()
+        worst = L.ph_walker_compact_check(size.ctypes.data_as(D), nom.ctypes.data_as(D), ctypes.byref(err))
+        assert err.value < 1e-15, (worst, err.value, size)   # rounding of zero offsets
