@@ -126,6 +126,7 @@ struct Scratch {   // per-lane working set of one forward evaluation
   T com[3];                       // subtree COM of the root (MuJoCo's reference point)
   T cinert[NBODY][10], cvel[NBODY][6], cdof[NV][6], cdofdot[NV][6];
   T anchor[NV][3], axis[NV][3];   // world frame joint anchor / axis per dof
+  T gpos[NGEOM][3], gaxis[NGEOM][3];   // world pose of every geom (computed once per evaluation)
   T M[NV][NV];                    // lower triangle; after factor: L^T D L in place
   T qfrc_bias[NV], qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV];
   // contacts
@@ -315,10 +316,11 @@ REX_HD void plane_sphere(Scratch<T>& s, const Model<T>& m, int p, const T* c, T 
 template <class T>
 REX_HD void collide(const Model<T>& m, Scratch<T>& s) {
   s.ncon = 0;
+  for (int g = 1; g < NGEOM; g++) geom_pose(m, s, g, s.gpos[g], s.gaxis[g]);   // 17 poses instead of 2 per pair (126 pairs)
   for (int p = 0; p < m.npair; p++) {
     int g1 = m.pair_g1[p], g2 = m.pair_g2[p], t1 = m.geom_type[g1], t2 = m.geom_type[g2];
     T p1[3], a1[3], p2[3], a2[3];
-    geom_pose(m, s, g2, p2, a2);
+    for (int k = 0; k < 3; k++) { p2[k] = s.gpos[g2][k]; a2[k] = s.gaxis[g2][k]; }
     T r2 = m.geom_rad[g2], l2 = m.geom_half[g2];
     if (t1 == G_PLANE) {
       if (p2[2] - r2 - l2 > m.margin) continue;                       // bounding sphere above the floor
@@ -330,7 +332,7 @@ REX_HD void collide(const Model<T>& m, Scratch<T>& s) {
       }
       continue;
     }
-    geom_pose(m, s, g1, p1, a1);
+    for (int k = 0; k < 3; k++) { p1[k] = s.gpos[g1][k]; a1[k] = s.gaxis[g1][k]; }
     T r1 = m.geom_rad[g1], l1 = m.geom_half[g1];
     T d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, reach = r1 + l1 + r2 + l2 + m.margin;
     if (dot3(d, d) > reach * reach) continue;                          // bounding spheres
@@ -470,25 +472,43 @@ REX_HD int solve_pgs(const Model<T>& m, Scratch<T>& s, T* qacc) {
 template <class T>
 struct ForwardOut { T xipos_x[NBODY]; };
 
+#ifndef REX_STAMP
+#define REX_STAMP(var) ((void)0)
+#define REX_TACC(slot, t0, t1) ((void)0)
+#endif
+
 // [3P] mj_forward
 template <class T>
 REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Scratch<T>& s, T* qacc) {
   s.overflow = 0;
+  REX_STAMP(t0);
   kinematics(m, qpos, s);
+  REX_STAMP(t1); REX_TACC(8, t0, t1);
   com_pos(m, L, s);
+  REX_STAMP(t2); REX_TACC(9, t1, t2);
   crb(m, s);
+  REX_STAMP(t3); REX_TACC(10, t2, t3);
   com_vel_rne(m, L, qvel, s);
   for (int i = 0; i < NV; i++) s.qfrc_actuator[i] = 0;
   for (int u = 0; u < NU; u++) { T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); s.qfrc_actuator[m.act_dof[u]] += m.act_gear[u] * c; }   // ctrlrange, humanoid.xml:6
   for (int i = 0; i < NV; i++) s.qfrc_smooth[i] = -L.damping[i] * qvel[i] - s.qfrc_bias[i] + s.qfrc_actuator[i];
   for (int j = 1; j < NJNT; j++) s.qfrc_smooth[m.jnt_dadr[j]] -= m.jnt_stiff[j] * qpos[m.jnt_qadr[j]];   // springref 0
+  REX_STAMP(t4); REX_TACC(11, t3, t4);
   collide(m, s);
+  REX_STAMP(t5); REX_TACC(12, t4, t5);
   make_constraints(m, qpos, qvel, s);
+  REX_STAMP(t6); REX_TACC(13, t5, t6);
   factor(m, s);
   for (int i = 0; i < NV; i++) s.qacc_smooth[i] = s.qfrc_smooth[i];
   solve(m, s, s.qacc_smooth);
+  REX_STAMP(t7); REX_TACC(14, t6, t7);
   if (s.nefc == 0) { for (int i = 0; i < NV; i++) qacc[i] = s.qacc_smooth[i]; return 0; }
-  return solve_pgs(m, s, qacc);
+  int it = solve_pgs(m, s, qacc);
+  REX_STAMP(t8); REX_TACC(15, t7, t8); REX_TACC(16, t0, t8);
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_ktime[17], 1ull); atomicAdd(&g_ktime[18], (unsigned long long)s.nefc); atomicAdd(&g_ktime[19], (unsigned long long)it); }
+#endif
+  return it;
 }
 
 // [3P] mj_integratePos

@@ -682,7 +682,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
 
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
 // diagnostic build only: per-phase cycle stamps (s_memtime), summed per wave into g_ktime[]
-extern __device__ unsigned long long g_ktime[8];
+extern __device__ unsigned long long g_ktime[24];
 #define REX_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #define REX_TACC(slot, t0, t1) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[slot], (t1) - (t0)); } while (0)
 #else

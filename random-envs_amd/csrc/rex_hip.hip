@@ -30,10 +30,10 @@
 using namespace rex;
 
 #if defined(REX_KTIME)
-namespace rex { __device__ unsigned long long g_ktime[8]; }
+namespace rex { __device__ unsigned long long g_ktime[24]; }   // 0..7 planar phases, 8..23 humanoid phases
 extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build only (not in rex.h)
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_ktime), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-  unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_ktime), z, sizeof z); return 0; }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_ktime), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+  unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_ktime), z, sizeof z); return 0; }
 #endif
 #if defined(REX_KSTATS)
 namespace rex { __device__ unsigned long long g_kstats[8]; }
@@ -227,6 +227,10 @@ __device__ __forceinline__ void write_obs(const float (&q)[S::NV], const float (
     (obs + (size_t)k * B)[i] = o;
   });
 }
+
+template <class S>
+__device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepFlags& fl, const DRParams& dr, int resample,
+                                                  int reset_state, unsigned i, float* __restrict__ obs);
 
 template <class S>
 __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
@@ -662,7 +666,9 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
     case REX_HUMANOID: {
       static hum::Model<double> md; static hum::Model<float> mf; static bool built = false;
       if (!built) { hum::build_model(md); hum::convert_model(md, mf); built = true; }
-      HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hum), &mf, sizeof mf));
+      { hum::Model<float> up = mf;   // diagnostics: REX_HUM_ITERS caps the PGS sweeps (timing experiments only)
+        if (getenv("REX_HUM_ITERS")) up.iterations = atoi(getenv("REX_HUM_ITERS"));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hum), &up, sizeof up)); }
       for (int b = 0; b < 13; b++) h->nominal_xi[b] = (float)md.body_mass0[1 + b];          // random_humanoid.py:46
       for (int k = 0; k < 17; k++) h->nominal_xi[13 + k] = (float)md.dof_damping0[6 + k];   // :47
       if (variant) {   // random_humanoid_unmodeled.py:40-50: masses 1..4 and dampings 6..8 frozen at 0.8x
