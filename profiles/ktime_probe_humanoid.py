@@ -21,5 +21,6 @@ names = ["kinematics", "com_pos", "crb", "rne+forces", "collide", "make_constrai
 tot = sum(o[8:16])
 print("forward evals with rows (waves):", n, "mean nefc(lane0) %.1f  mean sweeps %.1f" % (o[18] / n, o[19] / n))
 for i, nm in enumerate(names): print("  %-18s %9.0f ticks/eval  %5.1f%%" % (nm, o[8 + i] / n, 100 * o[8 + i] / tot))
+print("  pgs split: build A %.0f, sweeps %.0f, qacc %.0f" % (o[20] / n, o[21] / n, o[22] / n))
 print("  sum %.0f   stamped whole %.0f" % (tot / n, o[16] / n))
 env.close()

@@ -24,8 +24,29 @@ constexpr int MAXPAIR = 128;
 constexpr int MAXCON = 24;  // contacts kept per evaluation
 constexpr int MAXEFC = 64;  // constraint rows kept per evaluation
 constexpr int NXI = 30, NOBS = 376;
+// dual-space PGS working set kept in LDS on the device (one column per lane): packed lower triangle of
+// A = J M^-1 J^T + diag(R) for up to DUAL_NMAX rows, then force, b = J qacc_smooth - aref
+constexpr int DUAL_NMAX = 21;
+constexpr int DUAL_F = DUAL_NMAX * (DUAL_NMAX + 1) / 2, DUAL_B = DUAL_F + DUAL_NMAX, DUAL_WORDS = DUAL_B + DUAL_NMAX;   // 273 words per lane
 
 enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
+
+// Compile-time dof tree of humanoid.xml (free root 0-5, abdomen 6-8, right leg 9-12, left leg 13-16, right arm 17-19,
+// left arm 20-22).  The mass-matrix code below is generated from these tables (static indices => registers, no
+// pointer chasing through the model); build_model() derives the same tables from the XML transcription and
+// check_topology() compares the two.
+constexpr int kDofParent[NV] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 8, 13, 14, 15, 5, 17, 18, 5, 20, 21};
+constexpr int kDofBody[NV] = {1, 1, 1, 1, 1, 1, 2, 2, 3, 4, 4, 4, 5, 7, 7, 7, 8, 10, 10, 11, 12, 12, 13};
+constexpr int kBodyParent[NBODY] = {0, 0, 1, 2, 3, 4, 5, 3, 7, 8, 1, 10, 1, 12};
+constexpr int dof_depth(int d) { int n = 0; while (kDofParent[d] >= 0) { d = kDofParent[d]; n++; } return n; }
+constexpr int m_row(int i) { int o = 0; for (int k = 0; k < i; k++) o += dof_depth(k) + 1; return o; }
+constexpr int MNNZ = m_row(NV);   // 185 = entries (i, j) with j an ancestor-or-self dof of i
+constexpr int midx(int i, int j) { return m_row(i) + dof_depth(j); }   // valid when j is an ancestor-or-self of i
+constexpr bool dof_is_anc_or_self(int j, int i) { while (i >= 0) { if (i == j) return true; i = kDofParent[i]; } return false; }
+template <int I, class F> REX_HD void for_anc(F&& f) {          // f(IC<j>) for every proper ancestor dof j of I, nearest first
+  if constexpr (kDofParent[I] >= 0) { f(IC<kDofParent[I]>{}); for_anc<kDofParent[I]>(f); }
+}
+template <int I, class F> REX_HD void for_anc_self(F&& f) { f(IC<I>{}); for_anc<I>(f); }
 
 // Compiled model (uniform across a batch; lives in __constant__ memory on the device)
 template <class T>
@@ -127,13 +148,31 @@ struct Scratch {   // per-lane working set of one forward evaluation
   T cinert[NBODY][10], cvel[NBODY][6], cdof[NV][6], cdofdot[NV][6];
   T anchor[NV][3], axis[NV][3];   // world frame joint anchor / axis per dof
   T gpos[NGEOM][3], gaxis[NGEOM][3];   // world pose of every geom (computed once per evaluation)
-  T M[NV][NV];                    // lower triangle; after factor: L^T D L in place
   T qfrc_bias[NV], qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV];
   // contacts
   int ncon; T cpos[MAXCON][3], cframe[MAXCON][9], cdist[MAXCON], cmu[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];
   // constraint rows
   int nefc; T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
   int overflow;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  T dual_host[DUAL_WORDS];
+#endif
+};
+
+// per-lane dual-PGS workspace: LDS on the device (word k of lane l at k * blockDim.x + l: conflict-free), plain array on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __shared__ float hum_lds[];
+template <class T> REX_HD T& dual(Scratch<T>&, int k) { static_assert(sizeof(T) == 4, "device path is fp32"); return hum_lds[k * blockDim.x + threadIdx.x]; }
+#else
+template <class T> REX_HD T& dual(Scratch<T>& s, int k) { return s.dual_host[k]; }
+#endif
+
+// Tree-sparse joint-space inertia, packed (midx).  After factor(): L^T D L in place with the diagonal holding 1/D.
+// Every index into it is a compile-time constant, so on the device it lives in registers (AGPRs as overflow).
+template <class T>
+struct MassFactor {
+  T a[MNNZ];
+  REX_HD T get(int i, int j) const { return dof_is_anc_or_self(j, i) ? a[midx(i, j)] : (dof_is_anc_or_self(i, j) ? a[midx(j, i)] : T(0)); }   // tests
 };
 
 template <class T>
@@ -205,21 +244,23 @@ REX_HD void com_pos(const Model<T>& m, const Lane<T>& L, Scratch<T>& s) {
   }
 }
 
-// [3P] mj_crb: composite rigid body -> M (lower triangle, dense storage)
+// [3P] mj_crb: composite rigid body -> M (packed tree-sparse lower triangle)
 template <class T>
-REX_HD void crb(const Model<T>& m, Scratch<T>& s) {
+REX_HD void crb(const Model<T>& m, const Scratch<T>& s, MassFactor<T>& F) {
   T crbI[NBODY][10];
-  for (int b = 0; b < NBODY; b++) for (int k = 0; k < 10; k++) crbI[b][k] = s.cinert[b][k];
-  for (int b = NBODY - 1; b > 0; b--) { int p = m.body_parent[b]; if (p > 0) for (int k = 0; k < 10; k++) crbI[p][k] += crbI[b][k]; }
-  for (int i = 0; i < NV; i++) for (int j = 0; j <= i; j++) s.M[i][j] = 0;
-  for (int i = 0; i < NV; i++) {
-    T buf[6]; mul_inert(buf, crbI[m.dof_body[i]], s.cdof[i]);
-    s.M[i][i] = m.dof_armature[i];
-    for (int j = i; j >= 0; j = m.dof_parent[j]) {
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) crbI[b][k] = s.cinert[b][k]; });
+  static_rfor<2, NBODY>([&](auto BB) { constexpr int b = BB, p = kBodyParent[b]; for (int k = 0; k < 10; k++) crbI[p][k] += crbI[b][k]; });
+  static_for<0, NV>([&](auto II) {
+    constexpr int i = II;
+    T ci[6], buf[6];
+    for (int k = 0; k < 6; k++) ci[k] = s.cdof[i][k];
+    mul_inert(buf, crbI[kDofBody[i]], ci);
+    for_anc_self<i>([&](auto JJ) {
+      constexpr int j = JJ;
       T a = 0; for (int k = 0; k < 6; k++) a += s.cdof[j][k] * buf[k];
-      s.M[i][j] += a;
-    }
-  }
+      F.a[midx(i, j)] = (i == j) ? a + m.dof_armature[i] : a;
+    });
+  });
 }
 
 // [3P] mj_comVel + mj_rne (flg_acc = 0): bias forces incl. gravity
@@ -251,23 +292,26 @@ REX_HD void com_vel_rne(const Model<T>& m, const Lane<T>& L, const T* qvel, Scra
   for (int i = 0; i < NV; i++) { T a = 0; const T* f = cfrc[m.dof_body[i]]; for (int k = 0; k < 6; k++) a += s.cdof[i][k] * f[k]; s.qfrc_bias[i] = a; }
 }
 
-// sparse L^T D L in place ([3P] mj_factorM): M[k][k] <- D_k, M[k][i] <- L_ki for ancestor dofs i of k
+// sparse L^T D L in place ([3P] mj_factorM): (k,k) <- 1/D_k, (k,i) <- L_ki for the ancestor dofs i of k
 template <class T>
-REX_HD void factor(const Model<T>& m, Scratch<T>& s) {
-  for (int k = NV - 1; k >= 0; k--) {
-    T inv = T(1) / s.M[k][k];
-    for (int i = m.dof_parent[k]; i >= 0; i = m.dof_parent[i]) {
-      T a = s.M[k][i] * inv;
-      for (int j = i; j >= 0; j = m.dof_parent[j]) s.M[i][j] -= a * s.M[k][j];
-      s.M[k][i] = a;
-    }
-  }
+REX_HD void factor(MassFactor<T>& F) {
+  static_rfor<0, NV>([&](auto KK) {
+    constexpr int k = KK;
+    const T inv = T(1) / F.a[midx(k, k)];
+    for_anc<k>([&](auto II) {
+      constexpr int i = II;
+      const T a = F.a[midx(k, i)] * inv;
+      for_anc_self<i>([&](auto JJ) { constexpr int j = JJ; F.a[midx(i, j)] -= a * F.a[midx(k, j)]; });
+      F.a[midx(k, i)] = a;
+    });
+    F.a[midx(k, k)] = inv;
+  });
 }
 template <class T>
-REX_HD void solve(const Model<T>& m, const Scratch<T>& s, T* x) {
-  for (int k = NV - 1; k >= 0; k--) for (int i = m.dof_parent[k]; i >= 0; i = m.dof_parent[i]) x[i] -= s.M[k][i] * x[k];
-  for (int k = 0; k < NV; k++) x[k] /= s.M[k][k];
-  for (int k = 0; k < NV; k++) for (int i = m.dof_parent[k]; i >= 0; i = m.dof_parent[i]) x[k] -= s.M[k][i] * x[i];
+REX_HD void solve(const MassFactor<T>& F, T (&x)[NV]) {
+  static_rfor<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II; x[i] -= F.a[midx(k, i)] * x[k]; }); });
+  static_for<0, NV>([&](auto KK) { constexpr int k = KK; x[k] *= F.a[midx(k, k)]; });
+  static_for<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II; x[k] -= F.a[midx(k, i)] * x[i]; }); });
 }
 
 // ---- collision ([3P] engine_collision_primitive) -----------------------------------------------------
@@ -444,12 +488,14 @@ REX_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, Sc
 
 // [3P] mj_solPGS on the dual, with qacc carried along: res_i = J_i qacc - aref_i + R_i f_i
 template <class T>
-REX_HD int solve_pgs(const Model<T>& m, Scratch<T>& s, T* qacc) {
+REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, Scratch<T>& s, T* qacc) {
   for (int k = 0; k < NV; k++) qacc[k] = s.qacc_smooth[k];
   for (int i = 0; i < s.nefc; i++) {
-    for (int k = 0; k < NV; k++) s.MiJ[i][k] = s.J[i][k];
-    solve(m, s, s.MiJ[i]);
-    T a = s.R[i]; for (int k = 0; k < NV; k++) a += s.J[i][k] * s.MiJ[i][k];
+    T x[NV], jr[NV];
+    for (int k = 0; k < NV; k++) { jr[k] = s.J[i][k]; x[k] = jr[k]; }
+    solve(F, x);
+    T a = s.R[i];
+    for (int k = 0; k < NV; k++) { s.MiJ[i][k] = x[k]; a += jr[k] * x[k]; }
     s.Adiag[i] = a; s.force[i] = 0;   // warmstart disabled (humanoid.xml:11)
   }
   const T scale = T(1) / (m.meaninertia * T(NV));
@@ -469,13 +515,60 @@ REX_HD int solve_pgs(const Model<T>& m, Scratch<T>& s, T* qacc) {
   return it;
 }
 
-template <class T>
-struct ForwardOut { T xipos_x[NBODY]; };
-
 #ifndef REX_STAMP
 #define REX_STAMP(var) ((void)0)
 #define REX_TACC(slot, t0, t1) ((void)0)
 #endif
+
+// The same Gauss-Seidel sweeps on the dual: res_i = sum_j A_ij f_j + b_i with A = J M^-1 J^T + diag(R),
+// b = J qacc_smooth - aref ([3P] mj_solPGS works on exactly this matrix).  A, f and b sit in the lane's LDS column, so a
+// sweep costs n^2 LDS reads instead of 2 n nv reads of J / M^-1 J^T rows from scratch (which miss every cache level);
+// J is read once per row pair to build A and once more for qacc = qacc_smooth + M^-1 J^T f.
+template <class T>
+REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Scratch<T>& s, T* qacc) {
+  const int n = s.nefc;
+  T qs[NV];
+  REX_STAMP(p0);
+  for (int k = 0; k < NV; k++) qs[k] = s.qacc_smooth[k];
+  for (int j = 0; j < n; j++) {
+    T x[NV], jr[NV];
+    for (int k = 0; k < NV; k++) { jr[k] = s.J[j][k]; x[k] = jr[k]; }
+    solve(F, x);
+    T b = -s.aref[j]; for (int k = 0; k < NV; k++) b += jr[k] * qs[k];
+    dual(s, DUAL_B + j) = b; dual(s, DUAL_F + j) = T(0);   // warmstart disabled (humanoid.xml:11)
+    const int tj = j * (j + 1) / 2;
+    for (int i = 0; i < j; i++) { T a = 0; for (int k = 0; k < NV; k++) a += s.J[i][k] * x[k]; dual(s, tj + i) = a; }
+    T a = s.R[j]; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
+    dual(s, tj + j) = a;
+  }
+  REX_STAMP(p1); REX_TACC(20, p0, p1);
+  const T scale = T(1) / (m.meaninertia * T(NV));
+  int it = 0;
+  for (; it < m.iterations; it++) {
+    T improvement = 0;
+    for (int i = 0; i < n; i++) {
+      const int ti = i * (i + 1) / 2;
+      T res = dual(s, DUAL_B + i);
+      for (int j = 0; j <= i; j++) res += dual(s, ti + j) * dual(s, DUAL_F + j);
+      for (int j = i + 1; j < n; j++) res += dual(s, j * (j + 1) / 2 + i) * dual(s, DUAL_F + j);
+      const T ad = dual(s, ti + i), old = dual(s, DUAL_F + i), nf = hmax(T(0), old - res / ad), df = nf - old;
+      dual(s, DUAL_F + i) = nf;
+      improvement -= T(0.5) * df * df * ad + df * res;
+    }
+    if (improvement * scale < m.tolerance) { it++; break; }
+  }
+  REX_STAMP(p2); REX_TACC(21, p1, p2);
+  T x[NV];
+  for (int k = 0; k < NV; k++) x[k] = 0;
+  for (int i = 0; i < n; i++) { const T f = dual(s, DUAL_F + i); s.force[i] = f; if (f != T(0)) for (int k = 0; k < NV; k++) x[k] += s.J[i][k] * f; }
+  solve(F, x);
+  for (int k = 0; k < NV; k++) qacc[k] = qs[k] + x[k];
+  REX_STAMP(p3); REX_TACC(22, p2, p3);
+  return it;
+}
+
+template <class T>
+struct ForwardOut { T xipos_x[NBODY]; };
 
 // [3P] mj_forward
 template <class T>
@@ -486,24 +579,25 @@ REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* 
   REX_STAMP(t1); REX_TACC(8, t0, t1);
   com_pos(m, L, s);
   REX_STAMP(t2); REX_TACC(9, t1, t2);
-  crb(m, s);
-  REX_STAMP(t3); REX_TACC(10, t2, t3);
   com_vel_rne(m, L, qvel, s);
   for (int i = 0; i < NV; i++) s.qfrc_actuator[i] = 0;
   for (int u = 0; u < NU; u++) { T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); s.qfrc_actuator[m.act_dof[u]] += m.act_gear[u] * c; }   // ctrlrange, humanoid.xml:6
   for (int i = 0; i < NV; i++) s.qfrc_smooth[i] = -L.damping[i] * qvel[i] - s.qfrc_bias[i] + s.qfrc_actuator[i];
   for (int j = 1; j < NJNT; j++) s.qfrc_smooth[m.jnt_dadr[j]] -= m.jnt_stiff[j] * qpos[m.jnt_qadr[j]];   // springref 0
-  REX_STAMP(t4); REX_TACC(11, t3, t4);
+  REX_STAMP(t3); REX_TACC(11, t2, t3);
   collide(m, s);
-  REX_STAMP(t5); REX_TACC(12, t4, t5);
+  REX_STAMP(t4); REX_TACC(12, t3, t4);
   make_constraints(m, qpos, qvel, s);
-  REX_STAMP(t6); REX_TACC(13, t5, t6);
-  factor(m, s);
-  for (int i = 0; i < NV; i++) s.qacc_smooth[i] = s.qfrc_smooth[i];
-  solve(m, s, s.qacc_smooth);
+  REX_STAMP(t5); REX_TACC(13, t4, t5);
+  // the mass matrix and its factor are built last so that their 185 registers are live only from here on
+  MassFactor<T> F;
+  crb(m, s, F);
+  REX_STAMP(t6); REX_TACC(10, t5, t6);
+  factor(F);
+  { T x[NV]; for (int i = 0; i < NV; i++) x[i] = s.qfrc_smooth[i]; solve(F, x); for (int i = 0; i < NV; i++) s.qacc_smooth[i] = x[i]; }
   REX_STAMP(t7); REX_TACC(14, t6, t7);
   if (s.nefc == 0) { for (int i = 0; i < NV; i++) qacc[i] = s.qacc_smooth[i]; return 0; }
-  int it = solve_pgs(m, s, qacc);
+  int it = s.nefc <= DUAL_NMAX ? solve_pgs_dual(m, F, s, qacc) : solve_pgs(m, F, s, qacc);   // the scratch-row variant only for rare pile-ups
   REX_STAMP(t8); REX_TACC(15, t7, t8); REX_TACC(16, t0, t8);
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
   if ((threadIdx.x & 63) == 0) { atomicAdd(&g_ktime[17], 1ull); atomicAdd(&g_ktime[18], (unsigned long long)s.nefc); atomicAdd(&g_ktime[19], (unsigned long long)it); }

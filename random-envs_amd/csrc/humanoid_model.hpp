@@ -170,12 +170,13 @@ inline void build_model(Model<double>& m) {
   Lane<double> L; L.mass[0] = 0; for (int b = 1; b < NBODY; b++) L.mass[b] = m.body_mass0[b];
   for (int d = 0; d < NV; d++) L.damping[d] = m.dof_damping0[d];
   Scratch<double>* s = new Scratch<double>();
-  kinematics(m, m.qpos0, *s); com_pos(m, L, *s); crb(m, *s);
-  double tr = 0; for (int d = 0; d < NV; d++) tr += s->M[d][d];
+  kinematics(m, m.qpos0, *s); com_pos(m, L, *s);
+  MassFactor<double> F; crb(m, *s, F);
+  double tr = 0; for (int d = 0; d < NV; d++) tr += F.get(d, d);
   m.meaninertia = tr / NV;
-  factor(m, *s);
+  factor(F);
   double Minv[NV][NV];
-  for (int d = 0; d < NV; d++) { double e[NV] = {0}; e[d] = 1; solve(m, *s, e); for (int k = 0; k < NV; k++) Minv[k][d] = e[k]; }
+  for (int d = 0; d < NV; d++) { double e[NV] = {0}; e[d] = 1; solve(F, e); for (int k = 0; k < NV; k++) Minv[k][d] = e[k]; }
   for (int d = 0; d < NV; d++) m.dof_invw[d] = Minv[d][d];
   for (int g = 0; g < 2; g++) { double a = (m.dof_invw[3 * g] + m.dof_invw[3 * g + 1] + m.dof_invw[3 * g + 2]) / 3; for (int k = 0; k < 3; k++) m.dof_invw[3 * g + k] = a; }
   for (int b = 1; b < NBODY; b++) {
@@ -190,6 +191,14 @@ inline void build_model(Model<double>& m) {
     m.body_invw[b][0] = (A[0] + A[1] + A[2]) / 3; m.body_invw[b][1] = (A[3] + A[4] + A[5]) / 3;
   }
   delete s;
+}
+
+// the engine's compile-time tables (humanoid_engine.hpp) against the tables derived from the XML transcription above
+inline bool check_topology(const Model<double>& m) {
+  bool ok = true;
+  for (int d = 0; d < NV; d++) ok = ok && m.dof_parent[d] == kDofParent[d] && m.dof_body[d] == kDofBody[d];
+  for (int b = 0; b < NBODY; b++) ok = ok && m.body_parent[b] == kBodyParent[b];
+  return ok;
 }
 
 template <class T>

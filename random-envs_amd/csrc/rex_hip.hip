@@ -598,6 +598,8 @@ static int lanes_for(long long B) {
   if (e && atoi(e) > 0) return atoi(e);
   return B >= 65536 ? 64 : 32;
 }
+// dynamic LDS of the humanoid kernels: one dual-PGS column (hum::DUAL_WORDS floats) per lane
+static size_t hum_lds_bytes(long long B) { return sizeof(float) * hum::DUAL_WORDS * (size_t)lanes_for(B); }
 static unsigned grid_for(long long B) { int l = lanes_for(B); return (unsigned)((B + l - 1) / l); }
 
 static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st, int task_changed) {
@@ -665,10 +667,20 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
     case REX_HUMANOID: {
       static hum::Model<double> md; static hum::Model<float> mf; static bool built = false;
-      if (!built) { hum::build_model(md); hum::convert_model(md, mf); built = true; }
+      if (!built) {
+        hum::build_model(md);
+        if (!hum::check_topology(md)) return set_err(REX_ERR_ARG, "humanoid: compile-time dof tree differs from the model tables");
+        hum::convert_model(md, mf); built = true;
+      }
       { hum::Model<float> up = mf;   // diagnostics: REX_HUM_ITERS caps the PGS sweeps (timing experiments only)
         if (getenv("REX_HUM_ITERS")) up.iterations = atoi(getenv("REX_HUM_ITERS"));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hum), &up, sizeof up)); }
+      {   // 64-lane blocks need more than the default 64 KB of dynamic LDS
+        const int lds = (int)(sizeof(float) * hum::DUAL_WORDS * 64);
+        HIP_TRY(hipFuncSetAttribute((const void*)humanoid_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)humanoid_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)humanoid_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      }
       for (int b = 0; b < 13; b++) h->nominal_xi[b] = (float)md.body_mass0[1 + b];          // random_humanoid.py:46
       for (int k = 0; k < 17; k++) h->nominal_xi[13 + k] = (float)md.dof_damping0[6 + k];   // :47
       if (variant) {   // random_humanoid_unmodeled.py:40-50: masses 1..4 and dampings 6..8 frozen at 0.8x
@@ -695,7 +707,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
     HIP_TRY(hipMemcpy(h->d_scratch, q0, sizeof(float) * dims.nq, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.qpos, h->d_scratch, dims.nq, (long long)B);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, 0, h->dev, (float*)nullptr);
+    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), hum_lds_bytes(h->B), 0, h->dev, (float*)nullptr);
     HIP_TRY(hipGetLastError());
   }
   if (env_kind == REX_HOPPER || env_kind == REX_WALKER2D) {
@@ -772,7 +784,7 @@ static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, 
     case REX_HOPPER: hipLaunchKernelGGL(planar_reset_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
     case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_reset_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
     case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
-    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_reset_kernel, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_reset_kernel, g, b, hum_lds_bytes(h->B), st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
   }
   HIP_TRY(hipGetLastError());
   if (h->kind == REX_WALKER2D && resample) return launch_walker_derive(h, mask, bit, st, 1);
@@ -818,7 +830,7 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
     case REX_WALKER2D:
       hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
     case REX_HUMANOID:
-      hipLaunchKernelGGL(humanoid_step_kernel, g, b, 0, st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+      hipLaunchKernelGGL(humanoid_step_kernel, g, b, hum_lds_bytes(h->B), st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
   }
   if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
   HIP_TRY(hipGetLastError());
@@ -842,7 +854,7 @@ extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, voi
   rc = copy_rows(h->dev.qvel, qvel, h->dims.nv, h->B, (hipStream_t)stream); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(h->dev.done, 0, (size_t)h->B, (hipStream_t)stream));   // steps_beyond_done = None
   if (h->kind == REX_HUMANOID) {   // set_state runs sim.forward(): refreshes data.xipos (jinja_mujoco_env.py:154)
-    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, (hipStream_t)stream, h->dev, (float*)nullptr);
+    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), hum_lds_bytes(h->B), (hipStream_t)stream, h->dev, (float*)nullptr);
     HIP_TRY(hipGetLastError());
   }
   return REX_OK;
@@ -871,7 +883,7 @@ extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
     case REX_HOPPER: hipLaunchKernelGGL(planar_obs_kernel<HopperSpec>, g, b, 0, st, h->dev, obs_out); break;
     case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_obs_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, obs_out); break;
     case REX_WALKER2D: hipLaunchKernelGGL(planar_obs_kernel<Walker2dSpec>, g, b, 0, st, h->dev, obs_out); break;
-    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_forward_kernel, g, b, 0, st, h->dev, obs_out); break;
+    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_forward_kernel, g, b, hum_lds_bytes(h->B), st, h->dev, obs_out); break;
   }
   HIP_TRY(hipGetLastError());
   return REX_OK;

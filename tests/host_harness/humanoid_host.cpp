@@ -48,8 +48,9 @@ static void run_forward(const double* qpos, const double* qvel, const double* ct
   for (int k = 0; k < NV; k++) v[k] = T(qvel[k]);
   for (int k = 0; k < NU; k++) a[k] = T(ctrl[k]);
   // M before factorisation
-  kinematics(c->m, q, c->s); com_pos(c->m, L, c->s); crb(c->m, c->s);
-  for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) M[i * NV + j] = double(j <= i ? c->s.M[i][j] : c->s.M[j][i]);
+  kinematics(c->m, q, c->s); com_pos(c->m, L, c->s);
+  MassFactor<T> F; crb(c->m, c->s, F);
+  for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) M[i * NV + j] = double(F.get(i, j));
   int it = forward(c->m, L, q, v, a, c->s, acc);
   for (int k = 0; k < NV; k++) qacc[k] = double(acc[k]);
   info[0] = c->s.ncon; info[1] = c->s.nefc; info[2] = it; info[3] = c->s.overflow;
@@ -70,6 +71,7 @@ int hh_step(int f32, int n, const double* qpos, const double* qvel, const double
   else run_step<double>(n, qpos, qvel, act, xi, xprev, qpos_out, qvel_out, obs, reward, done, xout, overflow);
   return 0;
 }
+int hh_check_topology() { Model<double> md; build_model(md); return check_topology(md) ? 1 : 0; }
 int hh_forward(int f32, const double* qpos, const double* qvel, const double* ctrl, const double* xi, double* qacc, double* M, int* info) {
   if (f32) run_forward<float>(qpos, qvel, ctrl, xi, qacc, M, info); else run_forward<double>(qpos, qvel, ctrl, xi, qacc, M, info);
   return 0;

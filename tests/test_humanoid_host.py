@@ -50,6 +50,11 @@ def test_published_masses_and_model_compiler(hh):
     assert n_or == npair.value == 126 and np.allclose(bm, mass, rtol=1e-13)
 
 
+def test_compile_time_dof_tree_matches_model_tables(hh):
+    """the static mass-matrix code is generated from constexpr tables; they must agree with the XML transcription"""
+    assert hh.hh_check_topology() == 1
+
+
 def test_oracle_energy_conservation_3d():
     rng = np.random.RandomState(0)
     q = np.array([0, 0, 3.0, 1, 0, 0, 0] + [0] * 17, dtype=float); q[7:] += rng.uniform(-.3, .3, 17)
