@@ -24,10 +24,14 @@ constexpr int MAXPAIR = 128;
 constexpr int MAXCON = 24;  // contacts kept per evaluation
 constexpr int MAXEFC = 64;  // constraint rows kept per evaluation
 constexpr int NXI = 30, NOBS = 376;
-// dual-space PGS working set kept in LDS on the device (one column per lane): packed lower triangle of
-// A = J M^-1 J^T + diag(R) for up to DUAL_NMAX rows, then force, b = J qacc_smooth - aref
+// dual-space PGS working set kept in LDS on the device (one contiguous column per lane): the packed lower triangle of
+// A = J M^-1 J^T + diag(R) for up to DUAL_NMAX rows (0.09% of the evaluations of a random-policy batch have more than
+// 16 rows, none more than 21), then b = J qacc_smooth - aref and 1 / A_ii
 constexpr int DUAL_NMAX = 21;
-constexpr int DUAL_F = DUAL_NMAX * (DUAL_NMAX + 1) / 2, DUAL_B = DUAL_F + DUAL_NMAX, DUAL_WORDS = DUAL_B + DUAL_NMAX;   // 273 words per lane
+constexpr int tri(int i) { return i * (i + 1) / 2; }
+constexpr int DUAL_B = tri(DUAL_NMAX), DUAL_DI = DUAL_B + DUAL_NMAX;
+constexpr int DUAL_WORDS = 292;   // >= DUAL_DI + DUAL_NMAX and the geometry overlay; 4 blocks of 32 lanes fill a CU's 160 KB
+static_assert(DUAL_WORDS >= DUAL_DI + DUAL_NMAX && DUAL_WORDS % 8 == 4, "LDS column layout");
 
 enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
 
@@ -38,6 +42,15 @@ enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
 constexpr int kDofParent[NV] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 8, 13, 14, 15, 5, 17, 18, 5, 20, 21};
 constexpr int kDofBody[NV] = {1, 1, 1, 1, 1, 1, 2, 2, 3, 4, 4, 4, 5, 7, 7, 7, 8, 10, 10, 11, 12, 12, 13};
 constexpr int kBodyParent[NBODY] = {0, 0, 1, 2, 3, 4, 5, 3, 7, 8, 1, 10, 1, 12};
+constexpr int kBodyDofAdr[NBODY] = {0, 0, 6, 8, 9, 12, 0, 13, 16, 0, 17, 19, 20, 22};   // hinge dof d belongs to joint d - 5, qpos d + 1
+constexpr int kBodyDofNum[NBODY] = {0, 6, 2, 1, 3, 1, 0, 3, 1, 0, 2, 1, 2, 1};
+constexpr int kGeomBody[NGEOM] = {0, 1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 13};
+constexpr int kActDof[NU] = {7, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22};   // motors humanoid.xml:106-122
+constexpr int body_dof_mask(int b) {   // dofs that move body b
+  int mask = 0;
+  for (; b > 0; b = kBodyParent[b]) for (int k = 0; k < kBodyDofNum[b]; k++) mask |= 1 << (kBodyDofAdr[b] + k);
+  return mask;
+}
 constexpr int dof_depth(int d) { int n = 0; while (kDofParent[d] >= 0) { d = kDofParent[d]; n++; } return n; }
 constexpr int m_row(int i) { int o = 0; for (int k = 0; k < i; k++) o += dof_depth(k) + 1; return o; }
 constexpr int MNNZ = m_row(NV);   // 185 = entries (i, j) with j an ancestor-or-self dof of i
@@ -47,6 +60,10 @@ template <int I, class F> REX_HD void for_anc(F&& f) {          // f(IC<j>) for 
   if constexpr (kDofParent[I] >= 0) { f(IC<kDofParent[I]>{}); for_anc<kDofParent[I]>(f); }
 }
 template <int I, class F> REX_HD void for_anc_self(F&& f) { f(IC<I>{}); for_anc<I>(f); }
+
+// everything the pair loop needs about one candidate geom pair, as one record (a single wave-uniform load)
+template <class T>
+struct PairRec { int g1, g2, t1, t2, dim, mask1, mask2, b1, b2; T mu, r1, l1, r2, l2, tran; int pad; };
 
 // Compiled model (uniform across a batch; lives in __constant__ memory on the device)
 template <class T>
@@ -65,6 +82,7 @@ struct Model {
   T geom_pos[NGEOM][3], geom_axis[NGEOM][3], geom_rad[NGEOM], geom_half[NGEOM];
   int npair, pair_g1[MAXPAIR], pair_g2[MAXPAIR], pair_dim[MAXPAIR];
   T pair_mu[MAXPAIR];
+  PairRec<T> pair[MAXPAIR];     // the same pairs, packed for the device loop (fill_pair_records)
   int act_dof[NU]; T act_gear[NU];
   T qpos0[NQ];
   // solver constants: contacts and limits share solref (.02,1); solimp = MuJoCo default (.9,.95,.001)
@@ -141,31 +159,45 @@ struct Lane {   // randomised part of the model (xi)
   T damping[NV];      // dof_damping
 };
 
+// Static-index per-lane state of one forward evaluation: every access below uses compile-time indices, so the compiler
+// keeps it in registers and spills what has to survive the solver (the observation reads cinert / cvel / xipos /
+// qfrc_actuator of the LAST evaluation, random_humanoid.py:193-204).
 template <class T>
-struct Scratch {   // per-lane working set of one forward evaluation
-  T xpos[NBODY][3], xmat[NBODY][9], xquat[NBODY][4], xipos[NBODY][3];
+struct Kin {
+  T xmat[NBODY][9], xipos[NBODY][3];
   T com[3];                       // subtree COM of the root (MuJoCo's reference point)
-  T cinert[NBODY][10], cvel[NBODY][6], cdof[NV][6], cdofdot[NV][6];
-  T anchor[NV][3], axis[NV][3];   // world frame joint anchor / axis per dof
-  T gpos[NGEOM][3], gaxis[NGEOM][3];   // world pose of every geom (computed once per evaluation)
-  T qfrc_bias[NV], qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV];
-  // contacts
-  int ncon; T cpos[MAXCON][3], cframe[MAXCON][9], cdist[MAXCON], cmu[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];
-  // constraint rows
-  int nefc; T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
-  int overflow;
-#if !defined(__HIP_DEVICE_COMPILE__)
-  T dual_host[DUAL_WORDS];
-#endif
+  T cinert[NBODY][10], cvel[NBODY][6], cdof[NV][6];
+  T qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV];
 };
 
-// per-lane dual-PGS workspace: LDS on the device (word k of lane l at k * blockDim.x + l: conflict-free), plain array on the host
+// host stand-in for the lane's LDS column (empty for the fp32 device lanes)
+template <class T> struct HostColumn { alignas(16) T w[DUAL_WORDS]; };
 #if defined(__HIP_DEVICE_COMPILE__)
-extern __shared__ float hum_lds[];
-template <class T> REX_HD T& dual(Scratch<T>&, int k) { static_assert(sizeof(T) == 4, "device path is fp32"); return hum_lds[k * blockDim.x + threadIdx.x]; }
-#else
-template <class T> REX_HD T& dual(Scratch<T>& s, int k) { return s.dual_host[k]; }
+template <> struct HostColumn<float> {};
 #endif
+
+template <class T>
+struct Scratch {   // runtime-indexed per-lane arrays (HIP scratch): contacts and constraint rows
+  int ncon; T cpos[MAXCON][3], cframe[MAXCON][9], cdist[MAXCON], cmu[MAXCON], ctran[MAXCON];
+  int cdim[MAXCON], cmask1[MAXCON], cmask2[MAXCON], cb1[MAXCON], cb2[MAXCON];   // dof masks of the two body chains, body ids
+  int nefc; T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
+  int overflow;
+  HostColumn<T> col;
+};
+
+// Per-lane LDS column (DUAL_WORDS contiguous words); a plain array on the host.  It is used
+// twice per evaluation: first for the runtime-indexed geometry (geom poses for the pair loop, joint anchors / axes
+// for the contact Jacobians), then -- once the rows exist -- for the dual PGS working set.
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __shared__ __attribute__((aligned(16))) float hum_lds[];
+REX_HD float& dual(Scratch<float>&, int k) { return hum_lds[threadIdx.x * DUAL_WORDS + k]; }
+inline double& dual(Scratch<double>& s, int k) { return s.col.w[k]; }   // the fp64 model compiler (host code seen by the device pass)
+#else
+template <class T> REX_HD T& dual(Scratch<T>& s, int k) { return s.col.w[k]; }
+#endif
+constexpr int GEO_GEOM = 0;                        // (g - 1) * 6 + {pos 0..2, axis 3..5}, g = 1..17
+constexpr int GEO_DOF = (NGEOM - 1) * 6;           // i * 6 + {anchor 0..2, axis 3..5}, i = 0..22
+static_assert(GEO_DOF + NV * 6 <= DUAL_WORDS, "geometry overlay must fit the LDS column");
 
 // Tree-sparse joint-space inertia, packed (midx).  After factor(): L^T D L in place with the diagonal holding 1/D.
 // Every index into it is a compile-time constant, so on the device it lives in registers (AGPRs as overflow).
@@ -175,28 +207,31 @@ struct MassFactor {
   REX_HD T get(int i, int j) const { return dof_is_anc_or_self(j, i) ? a[midx(i, j)] : (dof_is_anc_or_self(i, j) ? a[midx(j, i)] : T(0)); }   // tests
 };
 
+// [3P] mj_kinematics, unrolled over the fixed tree.  Leaves xmat / xipos in K and the runtime-indexed geometry
+// (geom poses, dof anchors / axes) in the lane's LDS column.
 template <class T>
-REX_HD void kinematics(const Model<T>& m, const T* qpos, Scratch<T>& s) {
-  for (int k = 0; k < 3; k++) s.xpos[0][k] = 0;
-  s.xquat[0][0] = 1; s.xquat[0][1] = s.xquat[0][2] = s.xquat[0][3] = 0;
-  q2mat(s.xmat[0], s.xquat[0]);
-  for (int k = 0; k < 3; k++) s.xipos[0][k] = 0;
-  for (int b = 1; b < NBODY; b++) {
-    int p = m.body_parent[b];
+REX_HD void kinematics(const Model<T>& m, const T* qpos, Kin<T>& K, Scratch<T>& s) {
+  T xp[NBODY][3], xq[NBODY][4];
+  for (int k = 0; k < 3; k++) { xp[0][k] = 0; K.xipos[0][k] = 0; }
+  xq[0][0] = 1; xq[0][1] = xq[0][2] = xq[0][3] = 0;
+  q2mat(K.xmat[0], xq[0]);
+  static_for<1, NBODY>([&](auto BB) {
+    constexpr int b = BB, p = kBodyParent[b];
     T xpos[3], xquat[4], t[3], R[9];
-    mulv(t, s.xmat[p], m.body_pos[b]);
-    for (int k = 0; k < 3; k++) xpos[k] = s.xpos[p][k] + t[k];
-    qmul(xquat, s.xquat[p], m.body_quat[b]);
-    for (int jj = 0; jj < m.body_jntnum[b]; jj++) {
-      int j = m.body_jntadr[b] + jj, qa = m.jnt_qadr[j], da = m.jnt_dadr[j];
-      if (j == 0) {   // free joint of the torso
-        for (int k = 0; k < 3; k++) xpos[k] = qpos[k];
-        for (int k = 0; k < 4; k++) xquat[k] = qpos[3 + k];
-        qnorm(xquat); q2mat(R, xquat);
-        for (int k = 0; k < 3; k++) {
-          for (int x = 0; x < 3; x++) { s.axis[k][x] = (x == k) ? T(1) : T(0); s.anchor[k][x] = xpos[x]; s.axis[3 + k][x] = R[3 * x + k]; s.anchor[3 + k][x] = xpos[x]; }
-        }
-      } else {
+    if constexpr (b == 1) {   // free joint of the torso
+      for (int k = 0; k < 3; k++) xpos[k] = qpos[k];
+      for (int k = 0; k < 4; k++) xquat[k] = qpos[3 + k];
+      qnorm(xquat); q2mat(R, xquat);
+      for (int k = 0; k < 3; k++) for (int x = 0; x < 3; x++) {
+        dual(s, GEO_DOF + k * 6 + x) = xpos[x]; dual(s, GEO_DOF + k * 6 + 3 + x) = (x == k) ? T(1) : T(0);
+        dual(s, GEO_DOF + (3 + k) * 6 + x) = xpos[x]; dual(s, GEO_DOF + (3 + k) * 6 + 3 + x) = R[3 * x + k];
+      }
+    } else {
+      mulv(t, K.xmat[p], m.body_pos[b]);
+      for (int k = 0; k < 3; k++) xpos[k] = xp[p][k] + t[k];
+      qmul(xquat, xq[p], m.body_quat[b]);
+      static_for<0, kBodyDofNum[b]>([&](auto JJ) {
+        constexpr int da = kBodyDofAdr[b] + JJ, j = da - 5, qa = da + 1;
         q2mat(R, xquat);
         T anchor[3], axis[3];
         mulv(t, R, m.jnt_pos[j]); for (int k = 0; k < 3; k++) anchor[k] = xpos[k] + t[k];
@@ -206,58 +241,66 @@ REX_HD void kinematics(const Model<T>& m, const T* qpos, Scratch<T>& s) {
         qmul(nq, xquat, ql); for (int k = 0; k < 4; k++) xquat[k] = nq[k];
         qnorm(xquat); q2mat(R, xquat);
         mulv(t, R, m.jnt_pos[j]); for (int k = 0; k < 3; k++) xpos[k] = anchor[k] - t[k];
-        for (int k = 0; k < 3; k++) { s.axis[da][k] = axis[k]; s.anchor[da][k] = anchor[k]; }
-      }
+        for (int k = 0; k < 3; k++) { dual(s, GEO_DOF + da * 6 + k) = anchor[k]; dual(s, GEO_DOF + da * 6 + 3 + k) = axis[k]; }
+      });
     }
-    for (int k = 0; k < 3; k++) s.xpos[b][k] = xpos[k];
-    for (int k = 0; k < 4; k++) s.xquat[b][k] = xquat[k];
-    q2mat(s.xmat[b], xquat);
-    mulv(t, s.xmat[b], m.body_ipos[b]); for (int k = 0; k < 3; k++) s.xipos[b][k] = xpos[k] + t[k];
-  }
+    for (int k = 0; k < 3; k++) xp[b][k] = xpos[k];
+    for (int k = 0; k < 4; k++) xq[b][k] = xquat[k];
+    q2mat(K.xmat[b], xquat);
+    mulv(t, K.xmat[b], m.body_ipos[b]); for (int k = 0; k < 3; k++) K.xipos[b][k] = xpos[k] + t[k];
+  });
+  static_for<1, NGEOM>([&](auto GG) {   // geom poses for the pair loop
+    constexpr int g = GG, b = kGeomBody[g];
+    T t[3], a[3];
+    mulv(t, K.xmat[b], m.geom_pos[g]); mulv(a, K.xmat[b], m.geom_axis[g]);
+    for (int k = 0; k < 3; k++) { dual(s, GEO_GEOM + (g - 1) * 6 + k) = xp[b][k] + t[k]; dual(s, GEO_GEOM + (g - 1) * 6 + 3 + k) = a[k]; }
+  });
 }
 
 // [3P] mj_comPos: reference point, cinert, cdof
 template <class T>
-REX_HD void com_pos(const Model<T>& m, const Lane<T>& L, Scratch<T>& s) {
+REX_HD void com_pos(const Model<T>& m, const Lane<T>& L, Kin<T>& K, Scratch<T>& s) {
   T sc[3] = {0, 0, 0};
-  for (int b = 1; b < NBODY; b++) for (int k = 0; k < 3; k++) sc[k] += L.mass[b] * s.xipos[b][k];
-  for (int k = 0; k < 3; k++) s.com[k] = sc[k] / m.subtreemass_root;   // compile-time subtree mass (Q4-style staleness)
-  for (int k = 0; k < 10; k++) s.cinert[0][k] = 0;
-  for (int b = 1; b < NBODY; b++) {
-    const T* R = s.xmat[b]; const T* I = m.body_inertia[b];
+  static_for<1, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 3; k++) sc[k] += L.mass[b] * K.xipos[b][k]; });
+  for (int k = 0; k < 3; k++) K.com[k] = sc[k] / m.subtreemass_root;   // compile-time subtree mass (Q4-style staleness)
+  for (int k = 0; k < 10; k++) K.cinert[0][k] = 0;
+  static_for<1, NBODY>([&](auto BB) {
+    constexpr int b = BB;
+    const T* R = K.xmat[b]; const T* I = m.body_inertia[b];
     T Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, RI[9], Iw[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T a = 0; for (int k = 0; k < 3; k++) a += R[3 * i + k] * Ib[3 * k + j]; RI[3 * i + j] = a; }
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T a = 0; for (int k = 0; k < 3; k++) a += RI[3 * i + k] * R[3 * j + k]; Iw[3 * i + j] = a; }
-    T d[3] = {s.xipos[b][0] - s.com[0], s.xipos[b][1] - s.com[1], s.xipos[b][2] - s.com[2]}, ms = L.mass[b];
-    T* c = s.cinert[b];
+    T d[3] = {K.xipos[b][0] - K.com[0], K.xipos[b][1] - K.com[1], K.xipos[b][2] - K.com[2]}, ms = L.mass[b];
+    T* c = K.cinert[b];
     c[0] = Iw[0] + ms * (d[1] * d[1] + d[2] * d[2]); c[1] = Iw[4] + ms * (d[0] * d[0] + d[2] * d[2]); c[2] = Iw[8] + ms * (d[0] * d[0] + d[1] * d[1]);
     c[3] = Iw[1] - ms * d[0] * d[1]; c[4] = Iw[2] - ms * d[0] * d[2]; c[5] = Iw[5] - ms * d[1] * d[2];
     c[6] = ms * d[0]; c[7] = ms * d[1]; c[8] = ms * d[2]; c[9] = ms;
-  }
-  for (int i = 0; i < NV; i++) {
-    if (i < 3) { for (int k = 0; k < 3; k++) { s.cdof[i][k] = 0; s.cdof[i][3 + k] = s.axis[i][k]; } }
+  });
+  static_for<0, NV>([&](auto II) {
+    constexpr int i = II;
+    T anchor[3], axis[3];
+    for (int k = 0; k < 3; k++) { anchor[k] = dual(s, GEO_DOF + i * 6 + k); axis[k] = dual(s, GEO_DOF + i * 6 + 3 + k); }
+    if constexpr (i < 3) { for (int k = 0; k < 3; k++) { K.cdof[i][k] = 0; K.cdof[i][3 + k] = axis[k]; } }
     else {
-      T off[3] = {s.com[0] - s.anchor[i][0], s.com[1] - s.anchor[i][1], s.com[2] - s.anchor[i][2]}, t[3];
-      cross3(t, s.axis[i], off);
-      for (int k = 0; k < 3; k++) { s.cdof[i][k] = s.axis[i][k]; s.cdof[i][3 + k] = t[k]; }
+      T off[3] = {K.com[0] - anchor[0], K.com[1] - anchor[1], K.com[2] - anchor[2]}, t[3];
+      cross3(t, axis, off);
+      for (int k = 0; k < 3; k++) { K.cdof[i][k] = axis[k]; K.cdof[i][3 + k] = t[k]; }
     }
-  }
+  });
 }
 
 // [3P] mj_crb: composite rigid body -> M (packed tree-sparse lower triangle)
 template <class T>
-REX_HD void crb(const Model<T>& m, const Scratch<T>& s, MassFactor<T>& F) {
+REX_HD void crb(const Model<T>& m, const Kin<T>& K, MassFactor<T>& F) {
   T crbI[NBODY][10];
-  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) crbI[b][k] = s.cinert[b][k]; });
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) crbI[b][k] = K.cinert[b][k]; });
   static_rfor<2, NBODY>([&](auto BB) { constexpr int b = BB, p = kBodyParent[b]; for (int k = 0; k < 10; k++) crbI[p][k] += crbI[b][k]; });
   static_for<0, NV>([&](auto II) {
     constexpr int i = II;
-    T ci[6], buf[6];
-    for (int k = 0; k < 6; k++) ci[k] = s.cdof[i][k];
-    mul_inert(buf, crbI[kDofBody[i]], ci);
+    T buf[6]; mul_inert(buf, crbI[kDofBody[i]], K.cdof[i]);
     for_anc_self<i>([&](auto JJ) {
       constexpr int j = JJ;
-      T a = 0; for (int k = 0; k < 6; k++) a += s.cdof[j][k] * buf[k];
+      T a = 0; for (int k = 0; k < 6; k++) a += K.cdof[j][k] * buf[k];
       F.a[midx(i, j)] = (i == j) ? a + m.dof_armature[i] : a;
     });
   });
@@ -265,31 +308,29 @@ REX_HD void crb(const Model<T>& m, const Scratch<T>& s, MassFactor<T>& F) {
 
 // [3P] mj_comVel + mj_rne (flg_acc = 0): bias forces incl. gravity
 template <class T>
-REX_HD void com_vel_rne(const Model<T>& m, const Lane<T>& L, const T* qvel, Scratch<T>& s) {
-  T cacc[NBODY][6], cfrc[NBODY][6];
-  for (int k = 0; k < 6; k++) { s.cvel[0][k] = 0; cacc[0][k] = 0; }
+REX_HD void com_vel_rne(const Model<T>& m, const Lane<T>& L, const T* qvel, Kin<T>& K, T (&qfrc_bias)[NV]) {
+  T cacc[NBODY][6], cfrc[NBODY][6], cdofdot[NV][6];
+  for (int k = 0; k < 6; k++) { K.cvel[0][k] = 0; cacc[0][k] = 0; cfrc[0][k] = 0; }
   cacc[0][5] = m.gravity;   // -gravity: world accelerates upwards
-  for (int b = 1; b < NBODY; b++) {
-    int p = m.body_parent[b];
+  static_for<1, NBODY>([&](auto BB) {
+    constexpr int b = BB, p = kBodyParent[b], da = kBodyDofAdr[b], nd = kBodyDofNum[b];
     T v[6], a[6];
-    for (int k = 0; k < 6; k++) { v[k] = s.cvel[p][k]; a[k] = cacc[p][k]; }
-    int da = m.body_dofadr[b], nd = m.body_dofnum[b];
-    if (b == 1) {   // free joint: translations have cdofdot = 0; the three rotations use the velocity after the translations
-      for (int i = 0; i < 3; i++) { for (int k = 0; k < 6; k++) { s.cdofdot[i][k] = 0; v[k] += s.cdof[i][k] * qvel[i]; } }
-      for (int i = 3; i < 6; i++) cross_motion(s.cdofdot[i], v, s.cdof[i]);
-      for (int i = 3; i < 6; i++) for (int k = 0; k < 6; k++) v[k] += s.cdof[i][k] * qvel[i];
+    for (int k = 0; k < 6; k++) { v[k] = K.cvel[p][k]; a[k] = cacc[p][k]; }
+    if constexpr (b == 1) {   // free joint: translations have cdofdot = 0; the three rotations use the velocity after the translations
+      for (int i = 0; i < 3; i++) { for (int k = 0; k < 6; k++) { cdofdot[i][k] = 0; v[k] += K.cdof[i][k] * qvel[i]; } }
+      for (int i = 3; i < 6; i++) cross_motion(cdofdot[i], v, K.cdof[i]);
+      for (int i = 3; i < 6; i++) for (int k = 0; k < 6; k++) v[k] += K.cdof[i][k] * qvel[i];
     } else {
-      for (int jj = 0; jj < nd; jj++) { int i = da + jj; cross_motion(s.cdofdot[i], v, s.cdof[i]); for (int k = 0; k < 6; k++) v[k] += s.cdof[i][k] * qvel[i]; }
+      static_for<0, nd>([&](auto JJ) { constexpr int i = da + JJ; cross_motion(cdofdot[i], v, K.cdof[i]); for (int k = 0; k < 6; k++) v[k] += K.cdof[i][k] * qvel[i]; });
     }
-    for (int jj = 0; jj < nd; jj++) { int i = da + jj; for (int k = 0; k < 6; k++) a[k] += s.cdofdot[i][k] * qvel[i]; }
-    for (int k = 0; k < 6; k++) { s.cvel[b][k] = v[k]; cacc[b][k] = a[k]; }
+    static_for<0, nd>([&](auto JJ) { constexpr int i = da + JJ; for (int k = 0; k < 6; k++) a[k] += cdofdot[i][k] * qvel[i]; });
+    for (int k = 0; k < 6; k++) { K.cvel[b][k] = v[k]; cacc[b][k] = a[k]; }
     T Ia[6], Iv[6], t[6];
-    mul_inert(Ia, s.cinert[b], a); mul_inert(Iv, s.cinert[b], v); cross_force(t, v, Iv);
+    mul_inert(Ia, K.cinert[b], a); mul_inert(Iv, K.cinert[b], v); cross_force(t, v, Iv);
     for (int k = 0; k < 6; k++) cfrc[b][k] = Ia[k] + t[k];
-  }
-  for (int k = 0; k < 6; k++) cfrc[0][k] = 0;
-  for (int b = NBODY - 1; b > 0; b--) { int p = m.body_parent[b]; for (int k = 0; k < 6; k++) cfrc[p][k] += cfrc[b][k]; }
-  for (int i = 0; i < NV; i++) { T a = 0; const T* f = cfrc[m.dof_body[i]]; for (int k = 0; k < 6; k++) a += s.cdof[i][k] * f[k]; s.qfrc_bias[i] = a; }
+  });
+  static_rfor<1, NBODY>([&](auto BB) { constexpr int b = BB, p = kBodyParent[b]; for (int k = 0; k < 6; k++) cfrc[p][k] += cfrc[b][k]; });
+  static_for<0, NV>([&](auto II) { constexpr int i = II; T a = 0; for (int k = 0; k < 6; k++) a += K.cdof[i][k] * cfrc[kDofBody[i]][k]; qfrc_bias[i] = a; });
 }
 
 // sparse L^T D L in place ([3P] mj_factorM): (k,k) <- 1/D_k, (k,i) <- L_ki for the ancestor dofs i of k
@@ -316,12 +357,6 @@ REX_HD void solve(const MassFactor<T>& F, T (&x)[NV]) {
 
 // ---- collision ([3P] engine_collision_primitive) -----------------------------------------------------
 template <class T>
-REX_HD void geom_pose(const Model<T>& m, const Scratch<T>& s, int g, T* pos, T* axis) {
-  int b = m.geom_body[g]; T t[3];
-  mulv(t, s.xmat[b], m.geom_pos[g]); for (int k = 0; k < 3; k++) pos[k] = s.xpos[b][k] + t[k];
-  mulv(axis, s.xmat[b], m.geom_axis[g]);
-}
-template <class T>
 REX_HD void make_frame(T* f) {   // [3P] mju_makeFrame
   T n = hsqrt(dot3(f, f)); for (int k = 0; k < 3; k++) f[k] /= n;
   if (hsqrt(dot3(f + 3, f + 3)) < T(0.5)) { f[3] = f[4] = f[5] = 0; if (f[1] < T(0.5) && f[1] > T(-0.5)) f[4] = 1; else f[5] = 1; }
@@ -331,61 +366,63 @@ REX_HD void make_frame(T* f) {   // [3P] mju_makeFrame
   cross3(f + 6, f, f + 3);
 }
 template <class T>
-REX_HD void add_contact(Scratch<T>& s, const Model<T>& m, int p, T dist, const T* pos, const T* normal, const T* yaxis) {
+REX_HD void add_contact(Scratch<T>& s, const PairRec<T>& pr, T dist, const T* pos, const T* normal, const T* yaxis) {
   if (s.ncon >= MAXCON) { s.overflow = 1; return; }
   int c = s.ncon++;
-  s.cdist[c] = dist; s.cdim[c] = m.pair_dim[p]; s.cmu[c] = m.pair_mu[p];
-  s.cb1[c] = m.geom_body[m.pair_g1[p]]; s.cb2[c] = m.geom_body[m.pair_g2[p]];
-  for (int k = 0; k < 3; k++) { s.cpos[c][k] = pos[k]; s.cframe[c][k] = normal[k]; s.cframe[c][3 + k] = yaxis ? yaxis[k] : T(0); s.cframe[c][6 + k] = 0; }
-  make_frame(s.cframe[c]);
+  s.cdist[c] = dist; s.cdim[c] = pr.dim; s.cmu[c] = pr.mu; s.ctran[c] = pr.tran; s.cmask1[c] = pr.mask1; s.cmask2[c] = pr.mask2; s.cb1[c] = pr.b1; s.cb2[c] = pr.b2;
+  T f[9];
+  for (int k = 0; k < 3; k++) { f[k] = normal[k]; f[3 + k] = yaxis ? yaxis[k] : T(0); f[6 + k] = 0; }
+  make_frame(f);
+  for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
+  for (int k = 0; k < 9; k++) s.cframe[c][k] = f[k];
 }
 template <class T>
-REX_HD void sphere_sphere(Scratch<T>& s, const Model<T>& m, int p, const T* c1, T r1, const T* c2, T r2) {
+REX_HD void sphere_sphere(Scratch<T>& s, const Model<T>& m, const PairRec<T>& pr, const T* c1, T r1, const T* c2, T r2) {
   T d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
   T len = hsqrt(dot3(d, d)), dist = len - r1 - r2;
   if (dist > m.margin) return;
   T n[3] = {1, 0, 0};
   if (len >= T(1e-15)) { n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len; }
   T pos[3]; for (int k = 0; k < 3; k++) pos[k] = c1[k] + n[k] * (r1 + T(0.5) * dist);
-  add_contact(s, m, p, dist, pos, n, (const T*)nullptr);
+  add_contact(s, pr, dist, pos, n, (const T*)nullptr);
 }
 template <class T>
-REX_HD void plane_sphere(Scratch<T>& s, const Model<T>& m, int p, const T* c, T r, const T* yaxis) {
+REX_HD void plane_sphere(Scratch<T>& s, const Model<T>& m, const PairRec<T>& pr, const T* c, T r, const T* yaxis) {
   T n[3] = {0, 0, 1};                    // the floor: z = 0, normal +z (humanoid.xml:28)
   T dist = c[2] - r;
   if (dist > m.margin) return;
   T pos[3] = {c[0], c[1], c[2] - (r + T(0.5) * dist)};
-  add_contact(s, m, p, dist, pos, n, yaxis);
+  add_contact(s, pr, dist, pos, n, yaxis);
 }
 template <class T>
 REX_HD void collide(const Model<T>& m, Scratch<T>& s) {
   s.ncon = 0;
-  for (int g = 1; g < NGEOM; g++) geom_pose(m, s, g, s.gpos[g], s.gaxis[g]);   // 17 poses instead of 2 per pair (126 pairs)
   for (int p = 0; p < m.npair; p++) {
-    int g1 = m.pair_g1[p], g2 = m.pair_g2[p], t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    const PairRec<T>& pr = m.pair[p];   // one record per pair: a single uniform load
+    const int t1 = pr.t1, t2 = pr.t2;
     T p1[3], a1[3], p2[3], a2[3];
-    for (int k = 0; k < 3; k++) { p2[k] = s.gpos[g2][k]; a2[k] = s.gaxis[g2][k]; }
-    T r2 = m.geom_rad[g2], l2 = m.geom_half[g2];
+    for (int k = 0; k < 3; k++) { p2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + k); a2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + 3 + k); }
+    const T r2 = pr.r2, l2 = pr.l2;
     if (t1 == G_PLANE) {
       if (p2[2] - r2 - l2 > m.margin) continue;                       // bounding sphere above the floor
-      if (t2 == G_SPHERE) plane_sphere(s, m, p, p2, r2, (const T*)nullptr);
+      if (t2 == G_SPHERE) plane_sphere(s, m, pr, p2, r2, (const T*)nullptr);
       else {   // [3P] mjc_PlaneCapsule: the two end spheres, frame y-axis along the capsule
         T c[3];
-        for (int k = 0; k < 3; k++) c[k] = p2[k] + a2[k] * l2; plane_sphere(s, m, p, c, r2, a2);
-        for (int k = 0; k < 3; k++) c[k] = p2[k] - a2[k] * l2; plane_sphere(s, m, p, c, r2, a2);
+        for (int k = 0; k < 3; k++) c[k] = p2[k] + a2[k] * l2; plane_sphere(s, m, pr, c, r2, a2);
+        for (int k = 0; k < 3; k++) c[k] = p2[k] - a2[k] * l2; plane_sphere(s, m, pr, c, r2, a2);
       }
       continue;
     }
-    for (int k = 0; k < 3; k++) { p1[k] = s.gpos[g1][k]; a1[k] = s.gaxis[g1][k]; }
-    T r1 = m.geom_rad[g1], l1 = m.geom_half[g1];
+    for (int k = 0; k < 3; k++) { p1[k] = dual(s, GEO_GEOM + (pr.g1 - 1) * 6 + k); a1[k] = dual(s, GEO_GEOM + (pr.g1 - 1) * 6 + 3 + k); }
+    const T r1 = pr.r1, l1 = pr.l1;
     T d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, reach = r1 + l1 + r2 + l2 + m.margin;
     if (dot3(d, d) > reach * reach) continue;                          // bounding spheres
-    if (t1 == G_SPHERE && t2 == G_SPHERE) sphere_sphere(s, m, p, p1, r1, p2, r2);
+    if (t1 == G_SPHERE && t2 == G_SPHERE) sphere_sphere(s, m, pr, p1, r1, p2, r2);
     else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
       T x = -(d[0] * a2[0] + d[1] * a2[1] + d[2] * a2[2]);   // (p1 - p2).a2
       x = hmin(hmax(x, -l2), l2);
       T c2[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
-      sphere_sphere(s, m, p, p1, r1, c2, r2);
+      sphere_sphere(s, m, pr, p1, r1, c2, r2);
     } else {   // capsule-capsule ([3P] mjc_CapsuleCapsule)
       T dif[3] = {-d[0], -d[1], -d[2]};   // p1 - p2
       T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = ma * mc - mb * mb;
@@ -395,18 +432,18 @@ REX_HD void collide(const Model<T>& m, Scratch<T>& s) {
         if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) / ma; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) / ma; }
         if (x1 > l1) x1 = l1; else if (x1 < -l1) x1 = -l1;
         T c1[3], c2[3]; for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-        sphere_sphere(s, m, p, c1, r1, c2, r2);
+        sphere_sphere(s, m, pr, c1, r1, c2, r2);
       } else {   // parallel axes: end points of 1 against 2, then of 2 against 1 (<= 2 contacts)
         int n0 = s.ncon;
         for (int sg = -1; sg <= 1 && s.ncon - n0 < 2; sg += 2) {
           T c1[3], t[3]; for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * sg * l1; t[k] = c1[k] - p2[k]; }
           T x2 = dot3(t, a2);
-          if (x2 >= -l2 && x2 <= l2) { T c2[3]; for (int k = 0; k < 3; k++) c2[k] = p2[k] + a2[k] * x2; sphere_sphere(s, m, p, c1, r1, c2, r2); }
+          if (x2 >= -l2 && x2 <= l2) { T c2[3]; for (int k = 0; k < 3; k++) c2[k] = p2[k] + a2[k] * x2; sphere_sphere(s, m, pr, c1, r1, c2, r2); }
         }
         for (int sg = -1; sg <= 1 && s.ncon - n0 < 2; sg += 2) {
           T c2[3], t[3]; for (int k = 0; k < 3; k++) { c2[k] = p2[k] + a2[k] * sg * l2; t[k] = c2[k] - p1[k]; }
           T x1 = dot3(t, a1);
-          if (x1 >= -l1 && x1 <= l1) { T c1[3]; for (int k = 0; k < 3; k++) c1[k] = p1[k] + a1[k] * x1; sphere_sphere(s, m, p, c1, r1, c2, r2); }
+          if (x1 >= -l1 && x1 <= l1) { T c1[3]; for (int k = 0; k < 3; k++) c1[k] = p1[k] + a1[k] * x1; sphere_sphere(s, m, pr, c1, r1, c2, r2); }
         }
       }
     }
@@ -421,62 +458,72 @@ REX_HD T impedance3(const Model<T>& m, T x_abs) {   // power 2, midpoint .5
   return x >= T(1) ? m.dmax : imp;
 }
 
-// translational Jacobian row of a world point on body b projected on direction n:  out[dof] += sign * n . Jp
-template <class T>
-REX_HD void jac_dir(const Model<T>& m, const Scratch<T>& s, int b, const T* p, const T* n, T sign, T* out) {
-  for (; b > 0; b = m.body_parent[b]) {
-    for (int jj = 0; jj < m.body_dofnum[b]; jj++) {
-      int i = m.body_dofadr[b] + jj;
-      if (i < 3) out[i] += sign * n[i];
-      else { T r[3] = {p[0] - s.anchor[i][0], p[1] - s.anchor[i][1], p[2] - s.anchor[i][2]}, t[3]; cross3(t, s.axis[i], r); out[i] += sign * dot3(n, t); }
+// Translational Jacobian of a world point p, body-2 chain minus body-1 chain (dof masks), projected on NDIR directions
+// at once: out[d][i] = dir_d . (sign_i * axis_i x (p - anchor_i)).  One pass over the 23 dofs with compile-time indices;
+// dofs no lane of the wave needs are skipped.
+template <int NDIR, class T>
+REX_HD void jac_dirs(Scratch<T>& s, int mask1, int mask2, const T* p, const T* dirs, T (&out)[NDIR][NV]) {
+  static_for<0, NV>([&](auto II) {
+    constexpr int i = II;
+    const int in2 = (mask2 >> i) & 1, in1 = (mask1 >> i) & 1;
+    const T sign = T(in2 - in1);
+    for (int d = 0; d < NDIR; d++) out[d][i] = 0;
+    if (REX_WAVE_ANY(in2 != in1)) {
+      T col[3];
+      if constexpr (i < 3) { for (int k = 0; k < 3; k++) col[k] = (k == i) ? T(1) : T(0); }
+      else {
+        T r[3], ax[3];
+        for (int k = 0; k < 3; k++) { r[k] = p[k] - dual(s, GEO_DOF + i * 6 + k); ax[k] = dual(s, GEO_DOF + i * 6 + 3 + k); }
+        cross3(col, ax, r);
+      }
+      for (int d = 0; d < NDIR; d++) out[d][i] = sign * dot3(dirs + 3 * d, col);
     }
-  }
+  });
 }
 
 // [3P] mj_makeConstraint + mj_diagApprox + mj_makeImpedance + mj_referenceConstraint
 template <class T>
 REX_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, Scratch<T>& s) {
   int ne = 0;
-  for (int j = 1; j < NJNT; j++) {   // hinge limits (every hinge of the humanoid is limited, humanoid.xml:4)
-    T val = qpos[m.jnt_qadr[j]];
+  static_for<1, NJNT>([&](auto JJ) {   // hinge limits (every hinge of the humanoid is limited, humanoid.xml:4)
+    constexpr int j = JJ, d = j + 5;
+    const T val = qpos[j + 6];
     for (int side = -1; side <= 1; side += 2) {
       T dist = side * ((side < 0 ? m.jnt_lo[j] : m.jnt_hi[j]) - val);
       if (dist < T(0) && ne < MAXEFC) {
-        for (int k = 0; k < NV; k++) s.J[ne][k] = 0;
-        int d = m.jnt_dadr[j]; s.J[ne][d] = T(-side);
+        for (int k = 0; k < NV; k++) s.J[ne][k] = (k == d) ? T(-side) : T(0);
         T imp = impedance3(m, habs(dist));
         s.R[ne] = hmax(T(1e-15), (T(1) - imp) * m.dof_invw[d] / imp);
         s.aref[ne] = -m.B * (T(-side) * qvel[d]) - m.K * imp * dist;
         ne++;
       }
     }
-  }
+  });
   for (int c = 0; c < s.ncon; c++) {
     if (!(s.cdist[c] < m.margin)) continue;
-    int b1 = s.cb1[c], b2 = s.cb2[c];
-    T tran = m.body_invw[b1][0] + m.body_invw[b2][0];
+    const T tran = s.ctran[c];
     T imp = impedance3(m, habs(s.cdist[c] - m.margin));
     T kterm = m.K * imp * (s.cdist[c] - m.margin);
+    T pos[3], fr[9];
+    for (int k = 0; k < 3; k++) pos[k] = s.cpos[c][k];
+    for (int k = 0; k < 9; k++) fr[k] = s.cframe[c][k];
     if (s.cdim[c] == 1) {
       if (ne >= MAXEFC) { s.overflow = 1; break; }
-      for (int k = 0; k < NV; k++) s.J[ne][k] = 0;
-      jac_dir(m, s, b2, s.cpos[c], s.cframe[c], T(1), s.J[ne]); jac_dir(m, s, b1, s.cpos[c], s.cframe[c], T(-1), s.J[ne]);
+      T jn[1][NV];
+      jac_dirs<1>(s, s.cmask1[c], s.cmask2[c], pos, fr, jn);
+      T vel = 0; for (int k = 0; k < NV; k++) { s.J[ne][k] = jn[0][k]; vel += jn[0][k] * qvel[k]; }
       s.R[ne] = hmax(T(1e-15), (T(1) - imp) * tran / imp);
-      T vel = 0; for (int k = 0; k < NV; k++) vel += s.J[ne][k] * qvel[k];
       s.aref[ne] = -m.B * vel - kterm;
       ne++;
     } else {   // condim 3, pyramidal: n + mu t1, n - mu t1, n + mu t2, n - mu t2
       if (ne + 4 > MAXEFC) { s.overflow = 1; break; }
-      T jn[NV], jt[NV]; T mu = s.cmu[c];
-      for (int k = 0; k < NV; k++) jn[k] = 0;
-      jac_dir(m, s, b2, s.cpos[c], s.cframe[c], T(1), jn); jac_dir(m, s, b1, s.cpos[c], s.cframe[c], T(-1), jn);
+      T jf[3][NV]; const T mu = s.cmu[c];
+      jac_dirs<3>(s, s.cmask1[c], s.cmask2[c], pos, fr, jf);
       T R1 = hmax(T(1e-15), (T(1) - imp) * (tran + mu * mu * tran) / imp), Rpy = T(2) * mu * mu * R1;
       for (int t = 1; t <= 2; t++) {
-        for (int k = 0; k < NV; k++) jt[k] = 0;
-        jac_dir(m, s, b2, s.cpos[c], s.cframe[c] + 3 * t, T(1), jt); jac_dir(m, s, b1, s.cpos[c], s.cframe[c] + 3 * t, T(-1), jt);
         for (int sg = 1; sg >= -1; sg -= 2) {
           T vel = 0;
-          for (int k = 0; k < NV; k++) { T v = jn[k] + sg * mu * jt[k]; s.J[ne][k] = v; vel += v * qvel[k]; }
+          for (int k = 0; k < NV; k++) { T v = jf[0][k] + sg * mu * jf[t][k]; s.J[ne][k] = v; vel += v * qvel[k]; }
           s.R[ne] = Rpy; s.aref[ne] = -m.B * vel - kterm;
           ne++;
         }
@@ -486,10 +533,11 @@ REX_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, Sc
   s.nefc = ne;
 }
 
-// [3P] mj_solPGS on the dual, with qacc carried along: res_i = J_i qacc - aref_i + R_i f_i
+// [3P] mj_solPGS on the dual, with qacc carried along: res_i = J_i qacc - aref_i + R_i f_i.  Rows stay in scratch: only
+// used when an evaluation has more rows than the LDS column holds (pile-ups).
 template <class T>
-REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, Scratch<T>& s, T* qacc) {
-  for (int k = 0; k < NV; k++) qacc[k] = s.qacc_smooth[k];
+REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K, Scratch<T>& s, T* qacc) {
+  for (int k = 0; k < NV; k++) qacc[k] = K.qacc_smooth[k];
   for (int i = 0; i < s.nefc; i++) {
     T x[NV], jr[NV];
     for (int k = 0; k < NV; k++) { jr[k] = s.J[i][k]; x[k] = jr[k]; }
@@ -519,88 +567,161 @@ REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, Scratch<T>& s, T
 #define REX_STAMP(var) ((void)0)
 #define REX_TACC(slot, t0, t1) ((void)0)
 #endif
+// phase boundary: keeps the machine scheduler from interleaving two phases of forward() (which only lengthens live
+// ranges: 739 -> spilled VGPRs without it)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define REX_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define REX_FENCE() ((void)0)
+#endif
+
+#if defined(REX_PGS_FENCE) && defined(__HIP_DEVICE_COMPILE__)
+#define REX_PFENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define REX_PFENCE() ((void)0)
+#endif
+// keeps a batch of LDS reads together: all of them are issued, waited for once and held in registers from here on
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NOPIN)
+#define REX_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define REX_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#else
+#define REX_PIN4(a, b, c, d) ((void)0)
+#define REX_PIN2(a, b) ((void)0)
+#endif
+
+template <int Q, int NP, class T>
+REX_HD void pin_all(T (&a)[NP]) { if constexpr (Q < NP) { REX_PIN4(a[Q], a[Q + 1], a[Q + 2], a[Q + 3]); pin_all<Q + 4>(a); } }
+
+// Gauss-Seidel sweeps over rows / columns 0..NC-1 of the lane's packed A (NC a multiple of 4, or DUAL_NMAX).  The forces
+// live in registers and every index is a compile-time constant: a row update is one batch of LDS reads at fixed offsets
+// (no address arithmetic, no LDS write) followed by four short FMA chains.  Rows beyond the largest row count of the wave
+// are skipped; padding inside the range is zero, which makes its update a no-op.
+template <int NC, class T>
+REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX]) {
+  constexpr int NP = (NC + 3) / 4 * 4;
+  const T scale = T(1) / (m.meaninertia * T(NV));
+  int it = 0;
+  for (; it < m.iterations; it++) {
+    T improvement = 0;
+    static_for<0, NC>([&](auto II) {
+      constexpr int i = II;
+      if (REX_WAVE_ANY(i < n)) {
+        T a[NP];
+        static_for<0, NP>([&](auto JJ) { constexpr int j = JJ; a[j] = j < NC ? col[j <= i ? tri(i) + j : tri(j) + i] : T(0); });
+        T bi = col[DUAL_B + i], di = col[DUAL_DI + i];
+        pin_all<0>(a);
+        REX_PIN2(bi, di);
+        T r0 = bi, r1 = 0, r2 = 0, r3 = 0;
+        static_for<0, NP / 4>([&](auto QQ) {
+          constexpr int q = 4 * QQ;
+          r0 += a[q] * f[q]; if constexpr (q + 1 < NC) r1 += a[q + 1] * f[q + 1]; if constexpr (q + 2 < NC) r2 += a[q + 2] * f[q + 2]; if constexpr (q + 3 < NC) r3 += a[q + 3] * f[q + 3];
+        });
+        const T res = (r0 + r1) + (r2 + r3), old = f[i], nf = hmax(T(0), old - res * di), df = nf - old;
+        f[i] = nf;
+        improvement -= T(0.5) * df * df * a[i] + df * res;
+      }
+    });
+    if (improvement * scale < m.tolerance) { it++; break; }
+  }
+  return it;
+}
 
 // The same Gauss-Seidel sweeps on the dual: res_i = sum_j A_ij f_j + b_i with A = J M^-1 J^T + diag(R),
 // b = J qacc_smooth - aref ([3P] mj_solPGS works on exactly this matrix).  A, f and b sit in the lane's LDS column, so a
 // sweep costs n^2 LDS reads instead of 2 n nv reads of J / M^-1 J^T rows from scratch (which miss every cache level);
 // J is read once per row pair to build A and once more for qacc = qacc_smooth + M^-1 J^T f.
 template <class T>
-REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Scratch<T>& s, T* qacc) {
+REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K, Scratch<T>& s, T* qacc) {
   const int n = s.nefc;
-  T qs[NV];
-  REX_STAMP(p0);
-  for (int k = 0; k < NV; k++) qs[k] = s.qacc_smooth[k];
+  T* const col = (T*)__builtin_assume_aligned(&dual(s, 0), 16);
+  REX_PFENCE(); REX_STAMP(p0);
+  static_for<0, DUAL_DI + DUAL_NMAX>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
   for (int j = 0; j < n; j++) {
     T x[NV], jr[NV];
     for (int k = 0; k < NV; k++) { jr[k] = s.J[j][k]; x[k] = jr[k]; }
     solve(F, x);
-    T b = -s.aref[j]; for (int k = 0; k < NV; k++) b += jr[k] * qs[k];
-    dual(s, DUAL_B + j) = b; dual(s, DUAL_F + j) = T(0);   // warmstart disabled (humanoid.xml:11)
-    const int tj = j * (j + 1) / 2;
-    for (int i = 0; i < j; i++) { T a = 0; for (int k = 0; k < NV; k++) a += s.J[i][k] * x[k]; dual(s, tj + i) = a; }
-    T a = s.R[j]; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
-    dual(s, tj + j) = a;
-  }
-  REX_STAMP(p1); REX_TACC(20, p0, p1);
-  const T scale = T(1) / (m.meaninertia * T(NV));
-  int it = 0;
-  for (; it < m.iterations; it++) {
-    T improvement = 0;
-    for (int i = 0; i < n; i++) {
-      const int ti = i * (i + 1) / 2;
-      T res = dual(s, DUAL_B + i);
-      for (int j = 0; j <= i; j++) res += dual(s, ti + j) * dual(s, DUAL_F + j);
-      for (int j = i + 1; j < n; j++) res += dual(s, j * (j + 1) / 2 + i) * dual(s, DUAL_F + j);
-      const T ad = dual(s, ti + i), old = dual(s, DUAL_F + i), nf = hmax(T(0), old - res / ad), df = nf - old;
-      dual(s, DUAL_F + i) = nf;
-      improvement -= T(0.5) * df * df * ad + df * res;
+    T b = -s.aref[j]; for (int k = 0; k < NV; k++) b += jr[k] * K.qacc_smooth[k];
+    col[DUAL_B + j] = b;
+    T* const pa = col + tri(j);
+    int i = 0;
+    for (; i + 1 < j; i += 2) {   // two rows per trip: their scratch reads overlap
+      T a0 = 0, a1 = 0;
+      for (int k = 0; k < NV; k++) { a0 += s.J[i][k] * x[k]; a1 += s.J[i + 1][k] * x[k]; }
+      pa[i] = a0; pa[i + 1] = a1;
     }
-    if (improvement * scale < m.tolerance) { it++; break; }
+    if (i < j) { T a0 = 0; for (int k = 0; k < NV; k++) a0 += s.J[i][k] * x[k]; pa[i] = a0; }
+    T a = s.R[j]; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
+    pa[j] = a; col[DUAL_DI + j] = T(1) / a;
   }
-  REX_STAMP(p2); REX_TACC(21, p1, p2);
+  REX_PFENCE(); REX_STAMP(p1); REX_TACC(20, p0, p1);
+  // Sweeps over the smallest of three fixed sizes that holds every lane of the wave.
+  int it;
+  T f[DUAL_NMAX];
+  static_for<0, DUAL_NMAX>([&](auto II) { f[II] = T(0); });
+  {
+    int lvl = REX_WAVE_ANY(n > 16) ? 2 : (REX_WAVE_ANY(n > 8) ? 1 : 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    lvl = __builtin_amdgcn_readfirstlane(lvl);
+#endif
+    switch (lvl) {
+      case 0: it = pgs_sweeps<8>(m, col, n, f); break;
+      case 1: it = pgs_sweeps<16>(m, col, n, f); break;
+      default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
+    }
+  }
+  REX_PFENCE(); REX_STAMP(p2); REX_TACC(21, p1, p2);
   T x[NV];
   for (int k = 0; k < NV; k++) x[k] = 0;
-  for (int i = 0; i < n; i++) { const T f = dual(s, DUAL_F + i); s.force[i] = f; if (f != T(0)) for (int k = 0; k < NV; k++) x[k] += s.J[i][k] * f; }
+  static_for<0, DUAL_NMAX>([&](auto II) {
+    constexpr int i = II;
+    if (i < n) { const T fi = f[i]; s.force[i] = fi; if (fi != T(0)) for (int k = 0; k < NV; k++) x[k] += s.J[i][k] * fi; }
+  });
   solve(F, x);
-  for (int k = 0; k < NV; k++) qacc[k] = qs[k] + x[k];
+  for (int k = 0; k < NV; k++) qacc[k] = K.qacc_smooth[k] + x[k];
   REX_STAMP(p3); REX_TACC(22, p2, p3);
   return it;
 }
 
-template <class T>
-struct ForwardOut { T xipos_x[NBODY]; };
-
 // [3P] mj_forward
 template <class T>
-REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Scratch<T>& s, T* qacc) {
+REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc) {
   s.overflow = 0;
   REX_STAMP(t0);
-  kinematics(m, qpos, s);
-  REX_STAMP(t1); REX_TACC(8, t0, t1);
-  com_pos(m, L, s);
-  REX_STAMP(t2); REX_TACC(9, t1, t2);
-  com_vel_rne(m, L, qvel, s);
-  for (int i = 0; i < NV; i++) s.qfrc_actuator[i] = 0;
-  for (int u = 0; u < NU; u++) { T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); s.qfrc_actuator[m.act_dof[u]] += m.act_gear[u] * c; }   // ctrlrange, humanoid.xml:6
-  for (int i = 0; i < NV; i++) s.qfrc_smooth[i] = -L.damping[i] * qvel[i] - s.qfrc_bias[i] + s.qfrc_actuator[i];
-  for (int j = 1; j < NJNT; j++) s.qfrc_smooth[m.jnt_dadr[j]] -= m.jnt_stiff[j] * qpos[m.jnt_qadr[j]];   // springref 0
-  REX_STAMP(t3); REX_TACC(11, t2, t3);
+  kinematics(m, qpos, K, s);
+  REX_FENCE(); REX_STAMP(t1); REX_TACC(8, t0, t1);
+  com_pos(m, L, K, s);
+  REX_FENCE(); REX_STAMP(t2); REX_TACC(9, t1, t2);
+  {
+    T qfrc_bias[NV];
+    com_vel_rne(m, L, qvel, K, qfrc_bias);
+    static_for<0, NV>([&](auto II) { K.qfrc_actuator[II] = 0; });
+    static_for<0, NU>([&](auto UU) {   // motor u drives hinge kActJoint[u]; ctrlrange +-0.4 (humanoid.xml:6)
+      constexpr int u = UU; T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); K.qfrc_actuator[kActDof[u]] += m.act_gear[u] * c; });
+    static_for<0, NV>([&](auto II) { constexpr int i = II; K.qfrc_smooth[i] = -L.damping[i] * qvel[i] - qfrc_bias[i] + K.qfrc_actuator[i]; });
+    static_for<1, NJNT>([&](auto JJ) { constexpr int j = JJ; K.qfrc_smooth[j + 5] -= m.jnt_stiff[j] * qpos[j + 6]; });   // springref 0
+  }
+  REX_FENCE(); REX_STAMP(t3); REX_TACC(11, t2, t3);
   collide(m, s);
-  REX_STAMP(t4); REX_TACC(12, t3, t4);
+  REX_FENCE(); REX_STAMP(t4); REX_TACC(12, t3, t4);
   make_constraints(m, qpos, qvel, s);
-  REX_STAMP(t5); REX_TACC(13, t4, t5);
+  REX_FENCE(); REX_STAMP(t5); REX_TACC(13, t4, t5);
   // the mass matrix and its factor are built last so that their 185 registers are live only from here on
   MassFactor<T> F;
-  crb(m, s, F);
-  REX_STAMP(t6); REX_TACC(10, t5, t6);
+  crb(m, K, F);
+  REX_FENCE(); REX_STAMP(t6); REX_TACC(10, t5, t6);
   factor(F);
-  { T x[NV]; for (int i = 0; i < NV; i++) x[i] = s.qfrc_smooth[i]; solve(F, x); for (int i = 0; i < NV; i++) s.qacc_smooth[i] = x[i]; }
-  REX_STAMP(t7); REX_TACC(14, t6, t7);
-  if (s.nefc == 0) { for (int i = 0; i < NV; i++) qacc[i] = s.qacc_smooth[i]; return 0; }
-  int it = s.nefc <= DUAL_NMAX ? solve_pgs_dual(m, F, s, qacc) : solve_pgs(m, F, s, qacc);   // the scratch-row variant only for rare pile-ups
+  for (int i = 0; i < NV; i++) K.qacc_smooth[i] = K.qfrc_smooth[i];
+  solve(F, K.qacc_smooth);
+  REX_FENCE(); REX_STAMP(t7); REX_TACC(14, t6, t7);
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+  atomicAdd(&g_ktime[24 + (s.nefc < 71 ? s.nefc : 71)], 1ull);
+#endif
+  if (s.nefc == 0) { for (int i = 0; i < NV; i++) qacc[i] = K.qacc_smooth[i]; return 0; }
+  int it = s.nefc <= DUAL_NMAX ? solve_pgs_dual(m, F, K, s, qacc) : solve_pgs(m, F, K, s, qacc);   // the scratch-row variant only for rare pile-ups
   REX_STAMP(t8); REX_TACC(15, t7, t8); REX_TACC(16, t0, t8);
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_ktime[17], 1ull); atomicAdd(&g_ktime[18], (unsigned long long)s.nefc); atomicAdd(&g_ktime[19], (unsigned long long)it); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_ktime[17], 1ull); atomicAdd(&g_ktime[18], (unsigned long long)s.nefc); atomicAdd(&g_ktime[19], (unsigned long long)it);
+    if (REX_WAVE_ANY(s.nefc > DUAL_NMAX)) atomicAdd(&g_ktime[23], 1ull); }
 #endif
   return it;
 }
@@ -619,16 +740,16 @@ REX_HD void integrate_pos(T* qpos, const T* qvel, T h) {
   for (int k = 0; k < 17; k++) qpos[7 + k] += h * qvel[6 + k];
 }
 
-// One mj_step with RK4 ([3P] mj_RungeKutta, N = 4).  `s` keeps the quantities of the LAST forward
+// One mj_step with RK4 ([3P] mj_RungeKutta, N = 4).  `K` keeps the quantities of the LAST forward
 // evaluation (stage 4), which is what the reference's observation / reward read (random_humanoid.py:161-216).
 template <class T>
-REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* ctrl, Scratch<T>& s) {
+REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s) {
   const T h = m.timestep;
   T q0[NQ], v0[NV], dq[NV], dv[NV], acc[NV];
   for (int k = 0; k < NQ; k++) q0[k] = qpos[k];
   for (int k = 0; k < NV; k++) { v0[k] = qvel[k]; dq[k] = 0; dv[k] = 0; }
   for (int stage = 0; stage < 4; stage++) {
-    forward(m, L, qpos, qvel, ctrl, s, acc);
+    forward(m, L, qpos, qvel, ctrl, K, s, acc);
     const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3), c = stage == 2 ? h : T(0.5) * h;
     for (int k = 0; k < NV; k++) { dq[k] += w * qvel[k]; dv[k] += w * acc[k]; }
     if (stage < 3) {
@@ -644,44 +765,43 @@ REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const
   }
 }
 
+// _get_obs (random_humanoid.py:193-204): qpos[2:], qvel, cinert, cvel, qfrc_actuator, cfrc_ext (= 0)
+template <class T, class ObsSink>
+REX_HD void emit_obs(const T* qpos, const T* qvel, const Kin<T>& K, ObsSink&& obs) {
+  static_for<2, NQ>([&](auto KK) { constexpr int k = KK; obs(k - 2, qpos[k]); });
+  static_for<0, NV>([&](auto KK) { constexpr int k = KK; obs(22 + k, qvel[k]); });
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; static_for<0, 10>([&](auto KK) { constexpr int k = KK; obs(45 + 10 * b + k, K.cinert[b][k]); }); });
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; static_for<0, 6>([&](auto KK) { constexpr int k = KK; obs(185 + 6 * b + k, K.cvel[b][k]); }); });
+  static_for<0, NV>([&](auto KK) { constexpr int k = KK; obs(269 + k, K.qfrc_actuator[k]); });
+  for (int k = 0; k < 84; k++) obs(292 + k, T(0));
+}
+
 // RandomHumanoidEnv.step + _get_obs (random_humanoid.py:161-216), noise-free.
 //   xipos_x: in = data.xipos[:,0] left by the previous forward (mass_center() reads it before do_simulation);
 //            out = the same after this step (stage-4 forward of the last mj_step).
 //   obs(k, value) is called for k = 0..375 in order.
 template <class T, class ObsSink>
-REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* action, T* xipos_x, Scratch<T>& s,
+REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* action, T* xipos_x, Kin<T>& K, Scratch<T>& s,
                      T& reward, bool& done, ObsSink&& obs) {
   T mt = 0, s0 = 0, s1 = 0, asq = 0;
   for (int b = 0; b < NBODY; b++) { mt += L.mass[b]; s0 += L.mass[b] * xipos_x[b]; }
   for (int u = 0; u < NU; u++) asq += action[u] * action[u];       // data.ctrl holds the raw action (:167)
-  for (int f = 0; f < 5; f++) substep(m, L, qpos, qvel, action, s);   // frame_skip 5 (:41)
-  for (int b = 0; b < NBODY; b++) { xipos_x[b] = s.xipos[b][0]; s1 += L.mass[b] * s.xipos[b][0]; }
+  for (int f = 0; f < 5; f++) substep(m, L, qpos, qvel, action, K, s);   // frame_skip 5 (:41)
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = K.xipos[b][0]; s1 += L.mass[b] * K.xipos[b][0]; });
   const T dt = m.timestep * T(5);
   reward = T(1.25) * (s1 / mt - s0 / mt) / dt - T(0.1) * asq - T(0) /* cfrc_ext = 0, SURVEY Q15 */ + T(5);
   done = (qpos[2] < T(1.0)) || (qpos[2] > T(2.0));                 // :173
-  int c = 0;
-  for (int k = 2; k < NQ; k++) obs(c++, qpos[k]);
-  for (int k = 0; k < NV; k++) obs(c++, qvel[k]);
-  for (int b = 0; b < NBODY; b++) for (int k = 0; k < 10; k++) obs(c++, s.cinert[b][k]);
-  for (int b = 0; b < NBODY; b++) for (int k = 0; k < 6; k++) obs(c++, s.cvel[b][k]);
-  for (int k = 0; k < NV; k++) obs(c++, s.qfrc_actuator[k]);
-  for (int k = 0; k < 84; k++) obs(c++, T(0));
+  emit_obs(qpos, qvel, K, obs);
 }
 
 // observation right after set_state / reset: sim.forward() at the given state (jinja_mujoco_env.py:146-154)
 template <class T, class ObsSink>
-REX_HD void env_reset_obs(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, T* xipos_x, Scratch<T>& s, ObsSink&& obs) {
+REX_HD void env_reset_obs(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, T* xipos_x, Kin<T>& K, Scratch<T>& s, ObsSink&& obs) {
   T ctrl[NU], acc[NV];
   for (int u = 0; u < NU; u++) ctrl[u] = 0;                        // sim.reset() zeroes data.ctrl
-  forward(m, L, qpos, qvel, ctrl, s, acc);
-  for (int b = 0; b < NBODY; b++) xipos_x[b] = s.xipos[b][0];
-  int c = 0;
-  for (int k = 2; k < NQ; k++) obs(c++, qpos[k]);
-  for (int k = 0; k < NV; k++) obs(c++, qvel[k]);
-  for (int b = 0; b < NBODY; b++) for (int k = 0; k < 10; k++) obs(c++, s.cinert[b][k]);
-  for (int b = 0; b < NBODY; b++) for (int k = 0; k < 6; k++) obs(c++, s.cvel[b][k]);
-  for (int k = 0; k < NV; k++) obs(c++, s.qfrc_actuator[k]);
-  for (int k = 0; k < 84; k++) obs(c++, T(0));
+  forward(m, L, qpos, qvel, ctrl, K, s, acc);
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = K.xipos[b][0]; });
+  emit_obs(qpos, qvel, K, obs);
 }
 
 }  // namespace hum

@@ -170,8 +170,9 @@ inline void build_model(Model<double>& m) {
   Lane<double> L; L.mass[0] = 0; for (int b = 1; b < NBODY; b++) L.mass[b] = m.body_mass0[b];
   for (int d = 0; d < NV; d++) L.damping[d] = m.dof_damping0[d];
   Scratch<double>* s = new Scratch<double>();
-  kinematics(m, m.qpos0, *s); com_pos(m, L, *s);
-  MassFactor<double> F; crb(m, *s, F);
+  Kin<double>* K = new Kin<double>();
+  kinematics(m, m.qpos0, *K, *s); com_pos(m, L, *K, *s);
+  MassFactor<double> F; crb(m, *K, F);
   double tr = 0; for (int d = 0; d < NV; d++) tr += F.get(d, d);
   m.meaninertia = tr / NV;
   factor(F);
@@ -181,23 +182,39 @@ inline void build_model(Model<double>& m) {
   for (int g = 0; g < 2; g++) { double a = (m.dof_invw[3 * g] + m.dof_invw[3 * g + 1] + m.dof_invw[3 * g + 2]) / 3; for (int k = 0; k < 3; k++) m.dof_invw[3 * g + k] = a; }
   for (int b = 1; b < NBODY; b++) {
     double A[6];
+    const int mask = body_dof_mask(b);
     for (int r = 0; r < 6; r++) {
-      double row[NV] = {0}, e[3] = {0, 0, 0}; e[r % 3] = 1;
-      if (r < 3) jac_dir(m, *s, b, s->xipos[b], e, 1.0, row);
-      else for (int bb = b; bb > 0; bb = m.body_parent[bb]) for (int jj = 0; jj < m.body_dofnum[bb]; jj++) { int i = m.body_dofadr[bb] + jj; if (i >= 3) row[i] = s->axis[i][r - 3]; }
-      double a = 0; for (int i = 0; i < NV; i++) for (int k = 0; k < NV; k++) a += row[i] * Minv[i][k] * row[k];
+      double row[1][NV], e[3] = {0, 0, 0}; e[r % 3] = 1;
+      if (r < 3) jac_dirs<1>(*s, 0, mask, K->xipos[b], e, row);
+      else for (int i = 0; i < NV; i++) row[0][i] = (i >= 3 && ((mask >> i) & 1)) ? dual(*s, GEO_DOF + i * 6 + 3 + (r - 3)) : 0.0;
+      double a = 0; for (int i = 0; i < NV; i++) for (int k = 0; k < NV; k++) a += row[0][i] * Minv[i][k] * row[0][k];
       A[r] = a;
     }
     m.body_invw[b][0] = (A[0] + A[1] + A[2]) / 3; m.body_invw[b][1] = (A[3] + A[4] + A[5]) / 3;
   }
-  delete s;
+  delete s; delete K;
+  // packed pair records for the device loop
+  for (int p = 0; p < m.npair; p++) {
+    PairRec<double>& r = m.pair[p];
+    const int g1 = m.pair_g1[p], g2 = m.pair_g2[p], b1 = m.geom_body[g1], b2 = m.geom_body[g2];
+    r.g1 = g1; r.g2 = g2; r.t1 = m.geom_type[g1]; r.t2 = m.geom_type[g2]; r.dim = m.pair_dim[p];
+    r.mask1 = body_dof_mask(b1); r.mask2 = body_dof_mask(b2); r.b1 = b1; r.b2 = b2; r.pad = 0;
+    r.mu = m.pair_mu[p]; r.r1 = m.geom_rad[g1]; r.l1 = m.geom_half[g1]; r.r2 = m.geom_rad[g2]; r.l2 = m.geom_half[g2];
+    r.tran = m.body_invw[b1][0] + m.body_invw[b2][0];
+  }
 }
 
 // the engine's compile-time tables (humanoid_engine.hpp) against the tables derived from the XML transcription above
 inline bool check_topology(const Model<double>& m) {
   bool ok = true;
   for (int d = 0; d < NV; d++) ok = ok && m.dof_parent[d] == kDofParent[d] && m.dof_body[d] == kDofBody[d];
-  for (int b = 0; b < NBODY; b++) ok = ok && m.body_parent[b] == kBodyParent[b];
+  for (int b = 0; b < NBODY; b++) {
+    ok = ok && m.body_parent[b] == kBodyParent[b] && m.body_dofnum[b] == kBodyDofNum[b];
+    if (m.body_dofnum[b] > 0) ok = ok && m.body_dofadr[b] == kBodyDofAdr[b];
+  }
+  for (int j = 1; j < NJNT; j++) ok = ok && m.jnt_dadr[j] == j + 5 && m.jnt_qadr[j] == j + 6;
+  for (int g = 0; g < NGEOM; g++) ok = ok && m.geom_body[g] == kGeomBody[g];
+  for (int u = 0; u < NU; u++) ok = ok && m.act_dof[u] == kActDof[u];
   return ok;
 }
 
@@ -214,6 +231,12 @@ inline void convert_model(const Model<double>& a, Model<T>& b) {
   CI(npair); CI(pair_g1); CI(pair_g2); CI(pair_dim); CP(pair_mu); CI(act_dof); CP(act_gear); CP(qpos0);
   CP(K); CP(B); CP(dmin); CP(dmax); CP(width); CP(margin); CP(timestep); CP(gravity); CP(meaninertia); CP(tolerance);
   CI(iterations);
+  for (int p = 0; p < MAXPAIR; p++) {
+    const PairRec<double>& x = a.pair[p]; PairRec<T>& y = b.pair[p];
+    y.g1 = x.g1; y.g2 = x.g2; y.t1 = x.t1; y.t2 = x.t2; y.dim = x.dim; y.mask1 = x.mask1; y.mask2 = x.mask2; y.b1 = x.b1; y.b2 = x.b2;
+    y.mu = T(x.mu); y.r1 = T(x.r1); y.l1 = T(x.l1); y.r2 = T(x.r2); y.l2 = T(x.l2); y.tran = T(x.tran);
+    y.pad = 0;
+  }
 #undef CP
 #undef CI
 }

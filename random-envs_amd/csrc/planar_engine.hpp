@@ -357,12 +357,6 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
   });
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define REX_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
-#else
-#define REX_WAVE_ANY(x) (x)
-#endif
-
 // collision + constraint rows + reference accelerations  ([3P] mj_collision, mj_makeConstraint,
 // mj_diagApprox, mj_makeImpedance, mj_referenceConstraint)
 template <class T, class S>
@@ -682,7 +676,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
 
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
 // diagnostic build only: per-phase cycle stamps (s_memtime), summed per wave into g_ktime[]
-extern __device__ unsigned long long g_ktime[24];
+extern __device__ unsigned long long g_ktime[24 + 72];
 #define REX_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #define REX_TACC(slot, t0, t1) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[slot], (t1) - (t0)); } while (0)
 #else

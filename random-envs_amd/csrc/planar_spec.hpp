@@ -14,6 +14,13 @@
 #define REX_HD inline
 #endif
 
+// true if the predicate holds on any active lane of the wave (device); the predicate itself on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define REX_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define REX_WAVE_ANY(x) (x)
+#endif
+
 namespace rex {
 
 template <int N>

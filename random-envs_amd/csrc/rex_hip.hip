@@ -30,10 +30,10 @@
 using namespace rex;
 
 #if defined(REX_KTIME)
-namespace rex { __device__ unsigned long long g_ktime[24]; }   // 0..7 planar phases, 8..23 humanoid phases
+namespace rex { __device__ unsigned long long g_ktime[24 + 72]; }   // 0..7 planar phases, 8..23 humanoid phases, 24.. histogram of humanoid row counts
 extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build only (not in rex.h)
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_ktime), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
-  unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_ktime), z, sizeof z); return 0; }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_ktime), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
+  unsigned long long z[96] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_ktime), z, sizeof z); return 0; }
 #endif
 #if defined(REX_KSTATS)
 namespace rex { __device__ unsigned long long g_kstats[8]; }
@@ -414,13 +414,13 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
   for (int k = 0; k < hum::NV; k++) v[k] = (s.qvel + k * B)[i];
   for (int k = 0; k < hum::NU; k++) a[k] = (action + k * B)[i];
   for (int b = 0; b < hum::NBODY; b++) xp[b] = (s.aux + b * B)[i];
-  hum::Scratch<float> sc;
+  hum::Kin<float> kn; hum::Scratch<float> sc;
   float r; bool dn;
   rocrand_state_philox4x32_10 st;
   int t = s.t[i] + 1;
   if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
                              (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
-  hum::env_step(c_hum, L, q, v, a, xp, sc, r, dn, [&](int k, float val) {
+  hum::env_step(c_hum, L, q, v, a, xp, kn, sc, r, dn, [&](int k, float val) {
     // noise only on the qpos / qvel slices (random_humanoid.py:193-204)
     if (fl.noisy && k < 45) val += fl.noise_std * rocrand_normal(&st);
     (obs + k * B)[i] = val;
@@ -461,10 +461,10 @@ __global__ void __launch_bounds__(64) humanoid_reset_kernel(DevState s, StepFlag
     for (int k = 0; k < hum::NQ; k++) q[k] = c_hum.qpos0[k] + 0.01f * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
     for (int k = 0; k < hum::NV; k++) v[k] = 0.01f * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
     hum::Lane<float> L; hum_lane(s, i, L);
-    hum::Scratch<float> sc;
+    hum::Kin<float> kn; hum::Scratch<float> sc;
     rocrand_state_philox4x32_10 st2;
     if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + STEP_BASE, &st2);
-    hum::env_reset_obs(c_hum, L, q, v, xp, sc, [&](int k, float val) {
+    hum::env_reset_obs(c_hum, L, q, v, xp, kn, sc, [&](int k, float val) {
       if (fl.noisy && k < 45) val += fl.noise_std * rocrand_normal(&st2);
       if (obs) (obs + k * B)[i] = val;
     });
@@ -487,8 +487,8 @@ __global__ void __launch_bounds__(64) humanoid_forward_kernel(DevState s, float*
   for (int k = 0; k < hum::NQ; k++) q[k] = (s.qpos + k * B)[i];
   for (int k = 0; k < hum::NV; k++) v[k] = (s.qvel + k * B)[i];
   hum::Lane<float> L; hum_lane(s, i, L);
-  hum::Scratch<float> sc;
-  hum::env_reset_obs(c_hum, L, q, v, xp, sc, [&](int k, float val) { if (obs) (obs + k * B)[i] = val; });
+  hum::Kin<float> kn; hum::Scratch<float> sc;
+  hum::env_reset_obs(c_hum, L, q, v, xp, kn, sc, [&](int k, float val) { if (obs) (obs + k * B)[i] = val; });
   for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
 }
 

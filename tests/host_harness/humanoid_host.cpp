@@ -5,7 +5,7 @@
 
 using namespace rex::hum;
 
-template <class T> struct Ctx { Model<T> m; Scratch<T> s; };
+template <class T> struct Ctx { Model<T> m; Kin<T> k; Scratch<T> s; };
 template <class T> static Ctx<T>* ctx() {
   static Ctx<T>* c = nullptr;
   if (!c) { c = new Ctx<T>(); Model<double> md; build_model(md); convert_model(md, c->m); }
@@ -29,9 +29,9 @@ static void run_step(int n, const double* qpos, const double* qvel, const double
     for (int k = 0; k < NV; k++) v[k] = T(qvel[(size_t)k * n + i]);
     for (int k = 0; k < NU; k++) a[k] = T(act[(size_t)k * n + i]);
     if (xprev && xprev[i] == xprev[i]) for (int b = 0; b < NBODY; b++) xp[b] = T(xprev[(size_t)b * n + i]);
-    else env_reset_obs(c->m, L, q, v, xp, c->s, [](int, T) {});
+    else env_reset_obs(c->m, L, q, v, xp, c->k, c->s, [](int, T) {});
     T r; bool d;
-    env_step(c->m, L, q, v, a, xp, c->s, r, d, [&](int k, T val) { obs[(size_t)k * n + i] = double(val); });
+    env_step(c->m, L, q, v, a, xp, c->k, c->s, r, d, [&](int k, T val) { obs[(size_t)k * n + i] = double(val); });
     for (int k = 0; k < NQ; k++) qpos_out[(size_t)k * n + i] = double(q[k]);
     for (int k = 0; k < NV; k++) qvel_out[(size_t)k * n + i] = double(v[k]);
     reward[i] = double(r); done[i] = d; if (overflow) overflow[i] = c->s.overflow;
@@ -48,10 +48,10 @@ static void run_forward(const double* qpos, const double* qvel, const double* ct
   for (int k = 0; k < NV; k++) v[k] = T(qvel[k]);
   for (int k = 0; k < NU; k++) a[k] = T(ctrl[k]);
   // M before factorisation
-  kinematics(c->m, q, c->s); com_pos(c->m, L, c->s);
-  MassFactor<T> F; crb(c->m, c->s, F);
+  kinematics(c->m, q, c->k, c->s); com_pos(c->m, L, c->k, c->s);
+  MassFactor<T> F; crb(c->m, c->k, F);
   for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) M[i * NV + j] = double(F.get(i, j));
-  int it = forward(c->m, L, q, v, a, c->s, acc);
+  int it = forward(c->m, L, q, v, a, c->k, c->s, acc);
   for (int k = 0; k < NV; k++) qacc[k] = double(acc[k]);
   info[0] = c->s.ncon; info[1] = c->s.nefc; info[2] = it; info[3] = c->s.overflow;
 }
