@@ -1,5 +1,6 @@
-"""Diagnostic: per-phase cycle shares of the humanoid forward() from s_memtime stamps (build with -DREX_KTIME)."""
-import os, sys, ctypes
+"""Diagnostic: where a humanoid forward evaluation spends its time (build with -DREX_KTIME: s_memtime deltas summed in
+registers per lane, wave maximum flushed once per kernel).  Steady-state batch: episodes end (z < 1) and restart all the time."""
+import os, sys, ctypes, time
 os.environ["REX_LIB"] = "librex_hip_ktime.so"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, random_envs_amd as rex
@@ -10,23 +11,18 @@ nom = torch.tensor(env.original_task)
 env.set_dr_distribution("uniform", torch.stack([0.9 * nom, 1.1 * nom], 1).flatten().tolist()); env.set_dr_training(True); env.reset()
 g = torch.Generator().manual_seed(0)
 acts = [(torch.rand(env.dims.act_dim, B, generator=g) * 0.8 - 0.4).cuda() for _ in range(4)]
-for k in range(60): env.step_soa(acts[k % 4])   # steady state: episodes end (z < 1) and restart all the time
+for k in range(60): env.step_soa(acts[k % 4])
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 96)(); _native.lib().rex_debug_ktime(out)
-import time
 t0 = time.perf_counter()
 for k in range(8): env.step_soa(acts[k % 4])
 torch.cuda.synchronize()
 print("wall per step with stamps: %.2f ms" % ((time.perf_counter() - t0) / 8 * 1e3))
-_native.lib().rex_debug_ktime(out); o = list(out)
-n = o[17]
-names = ["kinematics", "com_pos", "crb", "rne+forces", "collide", "make_constraints", "factor+solve", "pgs(MiJ+sweeps)"]
-tot = sum(o[8:16])
-print("forward evals with rows (waves):", n, "mean nefc(lane0) %.1f  mean sweeps %.1f" % (o[18] / n, o[19] / n))
-for i, nm in enumerate(names): print("  %-18s %9.0f ticks/eval  %5.1f%%" % (nm, o[8 + i] / n, 100 * o[8 + i] / tot))
-print("  pgs split: build A %.0f, sweeps %.0f, qacc %.0f" % (o[20] / n, o[21] / n, o[22] / n))
-print("  evals where some lane of the wave took the scratch-row PGS (nefc > 21): %.1f%%" % (100.0 * o[23] / n))
-h = o[24:96]; tot_h = sum(h)
-print("  rows per evaluation (all lanes): " + " ".join("%d:%.2f%%" % (k, 100.0 * c / tot_h) for k, c in enumerate(h) if c))
-print("  sum %.0f   stamped whole %.0f" % (tot / n, o[16] / n))
+_native.lib().rex_debug_ktime(out); o = list(out)[8:24]
+names = ["kinematics+com+rne+forces", "limit rows", "broad phase", "narrow loop (incl. pair + rows)", "  inside collide_pair", "  inside add_contact",
+         "crb+factor+solve", "pgs: build A", "pgs: sweeps", "pgs: qacc", "whole forward"]
+n = o[11]
+print("wave-evaluations: %d; per evaluation: %.1f collide_pair calls, %.1f add_contact calls, %.1f sweeps (wave max), rows (wave max) %.1f" %
+      (n, o[12] / n, o[13] / n, o[14] / n, o[15] / n))
+for i, nm in enumerate(names): print("  %-34s %9.0f ticks/eval  %5.1f%%" % (nm, o[i] / n, 100.0 * o[i] / o[10]))
 env.close()

@@ -13,6 +13,20 @@
 
 #include "planar_spec.hpp"   // REX_HD
 
+// Diagnostic build (-DREX_KTIME): s_memtime deltas summed in per-lane registers (Kin::tacc) and flushed once per kernel by
+// the caller (wave maximum per slot), so the probes do not perturb what they measure.
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+#define REX_HSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define REX_HACC(K, slot, t0, t1) ((K).tacc[slot] += (t1) - (t0))
+#define REX_HCNT(K, slot, v) ((K).tacc[slot] += (unsigned long long)(v))
+#else
+#define REX_HSTAMP(var) ((void)0)
+#define REX_HACC(K, slot, t0, t1) ((void)0)
+#define REX_HCNT(K, slot, v) ((void)0)
+#endif
+enum { HT_SMOOTH = 0, HT_LIMITS, HT_BROAD, HT_NARROW_LOOP, HT_PAIR, HT_ROWS, HT_FACTOR, HT_BUILD_A, HT_SWEEPS, HT_QACC, HT_FORWARD,
+       HC_EVALS, HC_PAIR_CALLS, HC_ROW_CALLS, HC_SWEEPS, HC_NEFC, HT_SLOTS };
+
 namespace rex {
 namespace hum {
 
@@ -24,6 +38,7 @@ constexpr int MAXPAIR = 128;
 constexpr int MAXCON = 24;  // contacts kept per evaluation
 constexpr int MAXEFC = 64;  // constraint rows kept per evaluation
 constexpr int NXI = 30, NOBS = 376;
+enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
 // dual-space PGS working set kept in LDS on the device (one contiguous column per lane): the packed lower triangle of
 // A = J M^-1 J^T + diag(R) for up to DUAL_NMAX rows (0.09% of the evaluations of a random-policy batch have more than
 // 16 rows, none more than 21), then b = J qacc_smooth - aref and 1 / A_ii
@@ -33,7 +48,6 @@ constexpr int DUAL_B = tri(DUAL_NMAX), DUAL_DI = DUAL_B + DUAL_NMAX;
 constexpr int DUAL_WORDS = 292;   // >= DUAL_DI + DUAL_NMAX and the geometry overlay; 4 blocks of 32 lanes fill a CU's 160 KB
 static_assert(DUAL_WORDS >= DUAL_DI + DUAL_NMAX && DUAL_WORDS % 8 == 4, "LDS column layout");
 
-enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
 
 // Compile-time dof tree of humanoid.xml (free root 0-5, abdomen 6-8, right leg 9-12, left leg 13-16, right arm 17-19,
 // left arm 20-22).  The mass-matrix code below is generated from these tables (static indices => registers, no
@@ -45,6 +59,27 @@ constexpr int kBodyParent[NBODY] = {0, 0, 1, 2, 3, 4, 5, 3, 7, 8, 1, 10, 1, 12};
 constexpr int kBodyDofAdr[NBODY] = {0, 0, 6, 8, 9, 12, 0, 13, 16, 0, 17, 19, 20, 22};   // hinge dof d belongs to joint d - 5, qpos d + 1
 constexpr int kBodyDofNum[NBODY] = {0, 6, 2, 1, 3, 1, 0, 3, 1, 0, 2, 1, 2, 1};
 constexpr int kGeomBody[NGEOM] = {0, 1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 13};
+constexpr int kGeomType[NGEOM] = {0, 3, 2, 3, 3, 3, 3, 3, 2, 3, 3, 2, 3, 3, 2, 3, 3, 2};   // G_PLANE 0, G_SPHERE 2, G_CAPSULE 3
+// candidate geom pairs in MuJoCo's order ([3P] mj_collision): body pairs ascending, geoms of body 1 x geoms of body 2,
+// no pair inside one weld group (the feet have no joint: they belong to the shins) or between parent and child groups
+struct PairTable { int n; int g1[MAXPAIR], g2[MAXPAIR]; };
+constexpr PairTable make_pair_table() {
+  PairTable t{};
+  int weld[NBODY] = {};
+  for (int b = 1; b < NBODY; b++) weld[b] = kBodyDofNum[b] ? b : weld[kBodyParent[b]];
+  for (int b1 = 0; b1 < NBODY; b1++) for (int b2 = b1 + 1; b2 < NBODY; b2++) {
+    const int w1 = weld[b1], w2 = weld[b2], wp1 = weld[kBodyParent[w1]], wp2 = weld[kBodyParent[w2]];
+    if (w1 == w2) continue;
+    if (w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) continue;
+    for (int g1 = 0; g1 < NGEOM; g1++) for (int g2 = 0; g2 < NGEOM; g2++) {
+      if (kGeomBody[g1] != b1 || kGeomBody[g2] != b2) continue;
+      int a = g1, b = g2; if (kGeomType[a] > kGeomType[b]) { int x = a; a = b; b = x; }
+      t.g1[t.n] = a; t.g2[t.n] = b; t.n++;
+    }
+  }
+  return t;
+}
+constexpr PairTable kPairs = make_pair_table();
 constexpr int kActDof[NU] = {7, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22};   // motors humanoid.xml:106-122
 constexpr int body_dof_mask(int b) {   // dofs that move body b
   int mask = 0;
@@ -63,7 +98,7 @@ template <int I, class F> REX_HD void for_anc_self(F&& f) { f(IC<I>{}); for_anc<
 
 // everything the pair loop needs about one candidate geom pair, as one record (a single wave-uniform load)
 template <class T>
-struct PairRec { int g1, g2, t1, t2, dim, mask1, mask2, b1, b2; T mu, r1, l1, r2, l2, tran; int pad; };
+struct alignas(64) PairRec { int g1, g2, t1, t2, dim, mask1, mask2, b1, b2; T mu, r1, l1, r2, l2, tran; int pad; };
 
 // Compiled model (uniform across a batch; lives in __constant__ memory on the device)
 template <class T>
@@ -80,6 +115,7 @@ struct Model {
   T dof_armature[NV], dof_damping0[NV];
   int geom_type[NGEOM], geom_body[NGEOM];
   T geom_pos[NGEOM][3], geom_axis[NGEOM][3], geom_rad[NGEOM], geom_half[NGEOM];
+  T geom_bound[NGEOM];          // bounding-sphere radius: rad + half length
   int npair, pair_g1[MAXPAIR], pair_g2[MAXPAIR], pair_dim[MAXPAIR];
   T pair_mu[MAXPAIR];
   PairRec<T> pair[MAXPAIR];     // the same pairs, packed for the device loop (fill_pair_records)
@@ -168,6 +204,10 @@ struct Kin {
   T com[3];                       // subtree COM of the root (MuJoCo's reference point)
   T cinert[NBODY][10], cvel[NBODY][6], cdof[NV][6];
   T qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV];
+  int ncon, nefc, overflow;       // contacts / constraint rows of this evaluation; overflow: some were dropped (MAXCON / MAXEFC)
+#if defined(REX_KTIME)
+  unsigned long long tacc[HT_SLOTS];
+#endif
 };
 
 // host stand-in for the lane's LDS column (empty for the fp32 device lanes)
@@ -178,10 +218,8 @@ template <> struct HostColumn<float> {};
 
 template <class T>
 struct Scratch {   // runtime-indexed per-lane arrays (HIP scratch): contacts and constraint rows
-  int ncon; T cpos[MAXCON][3], cframe[MAXCON][9], cdist[MAXCON], cmu[MAXCON], ctran[MAXCON];
-  int cdim[MAXCON], cmask1[MAXCON], cmask2[MAXCON], cb1[MAXCON], cb2[MAXCON];   // dof masks of the two body chains, body ids
-  int nefc; T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
-  int overflow;
+  T cpos[MAXCON][3], cdist[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];   // contact log (written, never read back by the engine)
+  T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
   HostColumn<T> col;
 };
 
@@ -366,91 +404,6 @@ REX_HD void make_frame(T* f) {   // [3P] mju_makeFrame
   cross3(f + 6, f, f + 3);
 }
 template <class T>
-REX_HD void add_contact(Scratch<T>& s, const PairRec<T>& pr, T dist, const T* pos, const T* normal, const T* yaxis) {
-  if (s.ncon >= MAXCON) { s.overflow = 1; return; }
-  int c = s.ncon++;
-  s.cdist[c] = dist; s.cdim[c] = pr.dim; s.cmu[c] = pr.mu; s.ctran[c] = pr.tran; s.cmask1[c] = pr.mask1; s.cmask2[c] = pr.mask2; s.cb1[c] = pr.b1; s.cb2[c] = pr.b2;
-  T f[9];
-  for (int k = 0; k < 3; k++) { f[k] = normal[k]; f[3 + k] = yaxis ? yaxis[k] : T(0); f[6 + k] = 0; }
-  make_frame(f);
-  for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
-  for (int k = 0; k < 9; k++) s.cframe[c][k] = f[k];
-}
-template <class T>
-REX_HD void sphere_sphere(Scratch<T>& s, const Model<T>& m, const PairRec<T>& pr, const T* c1, T r1, const T* c2, T r2) {
-  T d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
-  T len = hsqrt(dot3(d, d)), dist = len - r1 - r2;
-  if (dist > m.margin) return;
-  T n[3] = {1, 0, 0};
-  if (len >= T(1e-15)) { n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len; }
-  T pos[3]; for (int k = 0; k < 3; k++) pos[k] = c1[k] + n[k] * (r1 + T(0.5) * dist);
-  add_contact(s, pr, dist, pos, n, (const T*)nullptr);
-}
-template <class T>
-REX_HD void plane_sphere(Scratch<T>& s, const Model<T>& m, const PairRec<T>& pr, const T* c, T r, const T* yaxis) {
-  T n[3] = {0, 0, 1};                    // the floor: z = 0, normal +z (humanoid.xml:28)
-  T dist = c[2] - r;
-  if (dist > m.margin) return;
-  T pos[3] = {c[0], c[1], c[2] - (r + T(0.5) * dist)};
-  add_contact(s, pr, dist, pos, n, yaxis);
-}
-template <class T>
-REX_HD void collide(const Model<T>& m, Scratch<T>& s) {
-  s.ncon = 0;
-  for (int p = 0; p < m.npair; p++) {
-    const PairRec<T>& pr = m.pair[p];   // one record per pair: a single uniform load
-    const int t1 = pr.t1, t2 = pr.t2;
-    T p1[3], a1[3], p2[3], a2[3];
-    for (int k = 0; k < 3; k++) { p2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + k); a2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + 3 + k); }
-    const T r2 = pr.r2, l2 = pr.l2;
-    if (t1 == G_PLANE) {
-      if (p2[2] - r2 - l2 > m.margin) continue;                       // bounding sphere above the floor
-      if (t2 == G_SPHERE) plane_sphere(s, m, pr, p2, r2, (const T*)nullptr);
-      else {   // [3P] mjc_PlaneCapsule: the two end spheres, frame y-axis along the capsule
-        T c[3];
-        for (int k = 0; k < 3; k++) c[k] = p2[k] + a2[k] * l2; plane_sphere(s, m, pr, c, r2, a2);
-        for (int k = 0; k < 3; k++) c[k] = p2[k] - a2[k] * l2; plane_sphere(s, m, pr, c, r2, a2);
-      }
-      continue;
-    }
-    for (int k = 0; k < 3; k++) { p1[k] = dual(s, GEO_GEOM + (pr.g1 - 1) * 6 + k); a1[k] = dual(s, GEO_GEOM + (pr.g1 - 1) * 6 + 3 + k); }
-    const T r1 = pr.r1, l1 = pr.l1;
-    T d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, reach = r1 + l1 + r2 + l2 + m.margin;
-    if (dot3(d, d) > reach * reach) continue;                          // bounding spheres
-    if (t1 == G_SPHERE && t2 == G_SPHERE) sphere_sphere(s, m, pr, p1, r1, p2, r2);
-    else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
-      T x = -(d[0] * a2[0] + d[1] * a2[1] + d[2] * a2[2]);   // (p1 - p2).a2
-      x = hmin(hmax(x, -l2), l2);
-      T c2[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
-      sphere_sphere(s, m, pr, p1, r1, c2, r2);
-    } else {   // capsule-capsule ([3P] mjc_CapsuleCapsule)
-      T dif[3] = {-d[0], -d[1], -d[2]};   // p1 - p2
-      T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = ma * mc - mb * mb;
-      if (habs(det) >= T(1e-15)) {
-        T x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-        if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) / mc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) / mc; }
-        if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) / ma; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) / ma; }
-        if (x1 > l1) x1 = l1; else if (x1 < -l1) x1 = -l1;
-        T c1[3], c2[3]; for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-        sphere_sphere(s, m, pr, c1, r1, c2, r2);
-      } else {   // parallel axes: end points of 1 against 2, then of 2 against 1 (<= 2 contacts)
-        int n0 = s.ncon;
-        for (int sg = -1; sg <= 1 && s.ncon - n0 < 2; sg += 2) {
-          T c1[3], t[3]; for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * sg * l1; t[k] = c1[k] - p2[k]; }
-          T x2 = dot3(t, a2);
-          if (x2 >= -l2 && x2 <= l2) { T c2[3]; for (int k = 0; k < 3; k++) c2[k] = p2[k] + a2[k] * x2; sphere_sphere(s, m, pr, c1, r1, c2, r2); }
-        }
-        for (int sg = -1; sg <= 1 && s.ncon - n0 < 2; sg += 2) {
-          T c2[3], t[3]; for (int k = 0; k < 3; k++) { c2[k] = p2[k] + a2[k] * sg * l2; t[k] = c2[k] - p1[k]; }
-          T x1 = dot3(t, a1);
-          if (x1 >= -l1 && x1 <= l1) { T c1[3]; for (int k = 0; k < 3; k++) c1[k] = p1[k] + a1[k] * x1; sphere_sphere(s, m, pr, c1, r1, c2, r2); }
-        }
-      }
-    }
-  }
-}
-
-template <class T>
 REX_HD T impedance3(const Model<T>& m, T x_abs) {   // power 2, midpoint .5
   T x = x_abs / m.width;
   T y = x < T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
@@ -481,11 +434,12 @@ REX_HD void jac_dirs(Scratch<T>& s, int mask1, int mask2, const T* p, const T* d
   });
 }
 
-// [3P] mj_makeConstraint + mj_diagApprox + mj_makeImpedance + mj_referenceConstraint
+// hinge-limit rows ([3P] mj_instantiateLimit; every hinge of the humanoid is limited, humanoid.xml:4).  They precede the
+// contact rows in MuJoCo's row order.
 template <class T>
-REX_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, Scratch<T>& s) {
+REX_HD void limit_rows(const Model<T>& m, const T* qpos, const T* qvel, Kin<T>& K, Scratch<T>& s) {
   int ne = 0;
-  static_for<1, NJNT>([&](auto JJ) {   // hinge limits (every hinge of the humanoid is limited, humanoid.xml:4)
+  static_for<1, NJNT>([&](auto JJ) {
     constexpr int j = JJ, d = j + 5;
     const T val = qpos[j + 6];
     for (int side = -1; side <= 1; side += 2) {
@@ -499,38 +453,180 @@ REX_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, Sc
       }
     }
   });
-  for (int c = 0; c < s.ncon; c++) {
-    if (!(s.cdist[c] < m.margin)) continue;
-    const T tran = s.ctran[c];
-    T imp = impedance3(m, habs(s.cdist[c] - m.margin));
-    T kterm = m.K * imp * (s.cdist[c] - m.margin);
-    T pos[3], fr[9];
-    for (int k = 0; k < 3; k++) pos[k] = s.cpos[c][k];
-    for (int k = 0; k < 9; k++) fr[k] = s.cframe[c][k];
-    if (s.cdim[c] == 1) {
-      if (ne >= MAXEFC) { s.overflow = 1; break; }
-      T jn[1][NV];
-      jac_dirs<1>(s, s.cmask1[c], s.cmask2[c], pos, fr, jn);
-      T vel = 0; for (int k = 0; k < NV; k++) { s.J[ne][k] = jn[0][k]; vel += jn[0][k] * qvel[k]; }
-      s.R[ne] = hmax(T(1e-15), (T(1) - imp) * tran / imp);
-      s.aref[ne] = -m.B * vel - kterm;
-      ne++;
-    } else {   // condim 3, pyramidal: n + mu t1, n - mu t1, n + mu t2, n - mu t2
-      if (ne + 4 > MAXEFC) { s.overflow = 1; break; }
-      T jf[3][NV]; const T mu = s.cmu[c];
-      jac_dirs<3>(s, s.cmask1[c], s.cmask2[c], pos, fr, jf);
-      T R1 = hmax(T(1e-15), (T(1) - imp) * (tran + mu * mu * tran) / imp), Rpy = T(2) * mu * mu * R1;
-      for (int t = 1; t <= 2; t++) {
-        for (int sg = 1; sg >= -1; sg -= 2) {
-          T vel = 0;
-          for (int k = 0; k < NV; k++) { T v = jf[0][k] + sg * mu * jf[t][k]; s.J[ne][k] = v; vel += v * qvel[k]; }
-          s.R[ne] = Rpy; s.aref[ne] = -m.B * vel - kterm;
-          ne++;
-        }
+  K.nefc = ne;
+}
+
+// A detected contact: recorded (diagnostics / tests) and, if inside the margin, turned into its constraint rows right away
+// while position and frame are still in registers ([3P] mj_instantiateContact + mj_diagApprox + mj_makeImpedance +
+// mj_referenceConstraint; pyramidal cone: n + mu t1, n - mu t1, n + mu t2, n - mu t2).
+template <class T>
+REX_HD void add_contact(Kin<T>& K, Scratch<T>& s, const Model<T>& m, const T* qvel, const PairRec<T>& pr, T dist, const T* pos, const T* normal, const T* yaxis) {
+  if (K.ncon >= MAXCON) { K.overflow = 1; return; }
+  int c = K.ncon++;
+  s.cdist[c] = dist; s.cdim[c] = pr.dim; s.cb1[c] = pr.b1; s.cb2[c] = pr.b2;
+  T f[9];
+  for (int k = 0; k < 3; k++) { f[k] = normal[k]; f[3 + k] = yaxis ? yaxis[k] : T(0); f[6 + k] = 0; }
+  make_frame(f);
+  for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
+  if (!(dist < m.margin)) return;
+  int ne = K.nefc;
+  const T tran = pr.tran, mu = pr.mu;
+  const T imp = impedance3(m, habs(dist - m.margin)), kterm = m.K * imp * (dist - m.margin);
+  if (pr.dim == 1) {
+    if (ne >= MAXEFC) { K.overflow = 1; return; }
+    T jn[1][NV];
+    jac_dirs<1>(s, pr.mask1, pr.mask2, pos, f, jn);
+    T vel = 0; for (int k = 0; k < NV; k++) { s.J[ne][k] = jn[0][k]; vel += jn[0][k] * qvel[k]; }
+    s.R[ne] = hmax(T(1e-15), (T(1) - imp) * tran / imp);
+    s.aref[ne] = -m.B * vel - kterm;
+    ne++;
+  } else {
+    if (ne + 4 > MAXEFC) { K.overflow = 1; return; }
+    T jf[3][NV];
+    jac_dirs<3>(s, pr.mask1, pr.mask2, pos, f, jf);
+    const T R1 = hmax(T(1e-15), (T(1) - imp) * (tran + mu * mu * tran) / imp), Rpy = T(2) * mu * mu * R1;
+    for (int t = 1; t <= 2; t++) {
+      for (int sg = 1; sg >= -1; sg -= 2) {
+        T vel = 0;
+        for (int k = 0; k < NV; k++) { T v = jf[0][k] + sg * mu * jf[t][k]; s.J[ne][k] = v; vel += v * qvel[k]; }
+        s.R[ne] = Rpy; s.aref[ne] = -m.B * vel - kterm;
+        ne++;
       }
     }
   }
-  s.nefc = ne;
+  K.nefc = ne;
+}
+// what the narrow phase found for one pair: at most two contacts (plane-capsule, parallel capsules)
+template <class T>
+struct Hits { int n; T dist[2], pos[2][3], normal[2][3]; };
+
+template <class T>
+REX_HD void sphere_sphere(Hits<T>& h, const Model<T>& m, const T* c1, T r1, const T* c2, T r2) {
+  T d[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  T len = hsqrt(dot3(d, d)), dist = len - r1 - r2;
+  if (dist > m.margin || h.n >= 2) return;
+  T n[3] = {1, 0, 0};
+  if (len >= T(1e-15)) { n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len; }
+  const bool first = h.n == 0; h.n++;
+  for (int x = 0; x < 3; x++) { const T px = c1[x] + n[x] * (r1 + T(0.5) * dist); if (first) { h.pos[0][x] = px; h.normal[0][x] = n[x]; } else { h.pos[1][x] = px; h.normal[1][x] = n[x]; } }
+  if (first) h.dist[0] = dist; else h.dist[1] = dist;
+}
+template <class T>
+REX_HD void plane_sphere(Hits<T>& h, const Model<T>& m, const T* c, T r) {
+  T dist = c[2] - r;                     // the floor: z = 0, normal +z (humanoid.xml:28)
+  if (dist > m.margin || h.n >= 2) return;
+  const bool first = h.n == 0; h.n++;
+  const T pz = c[2] - (r + T(0.5) * dist);
+  if (first) { h.dist[0] = dist; h.pos[0][0] = c[0]; h.pos[0][1] = c[1]; h.pos[0][2] = pz; h.normal[0][0] = 0; h.normal[0][1] = 0; h.normal[0][2] = 1; }
+  else { h.dist[1] = dist; h.pos[1][0] = c[0]; h.pos[1][1] = c[1]; h.pos[1][2] = pz; h.normal[1][0] = 0; h.normal[1][1] = 0; h.normal[1][2] = 1; }
+}
+
+// narrow phase of one candidate pair ([3P] engine_collision_primitive); yaxis = frame hint of the contacts (capsule axis for
+// plane-capsule, else none)
+template <class T>
+REX_HD void collide_pair(const Model<T>& m, Scratch<T>& s, const PairRec<T>& pr, Hits<T>& h, T (&yaxis)[3], bool& has_y) {
+  const int t1 = pr.t1, t2 = pr.t2;
+  h.n = 0; has_y = false;
+  T p1[3], a1[3], p2[3], a2[3];
+  for (int k = 0; k < 3; k++) { p2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + k); a2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + 3 + k); yaxis[k] = a2[k]; }
+  const T r2 = pr.r2, l2 = pr.l2;
+  if (t1 == G_PLANE) {
+    if (t2 == G_SPHERE) plane_sphere(h, m, p2, r2);
+    else {   // [3P] mjc_PlaneCapsule: the two end spheres, frame y-axis along the capsule
+      T c[3]; has_y = true;
+      for (int sg = 1; sg >= -1; sg -= 2) { for (int k = 0; k < 3; k++) c[k] = p2[k] + a2[k] * (sg * l2); plane_sphere(h, m, c, r2); }
+    }
+    return;
+  }
+  for (int k = 0; k < 3; k++) { p1[k] = dual(s, GEO_GEOM + (pr.g1 - 1) * 6 + k); a1[k] = dual(s, GEO_GEOM + (pr.g1 - 1) * 6 + 3 + k); }
+  const T r1 = pr.r1, l1 = pr.l1;
+  T d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  T c1[3] = {p1[0], p1[1], p1[2]}, c2[3] = {p2[0], p2[1], p2[2]};   // the two sphere centres the pair reduces to
+  bool single = true;
+  if (t1 == G_SPHERE && t2 == G_CAPSULE) {
+    T x = -(d[0] * a2[0] + d[1] * a2[1] + d[2] * a2[2]);   // (p1 - p2).a2
+    x = hmin(hmax(x, -l2), l2);
+    for (int k = 0; k < 3; k++) c2[k] = p2[k] + a2[k] * x;
+  } else if (t1 == G_CAPSULE) {   // capsule-capsule ([3P] mjc_CapsuleCapsule)
+    T dif[3] = {-d[0], -d[1], -d[2]};   // p1 - p2
+    T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = ma * mc - mb * mb;
+    if (habs(det) >= T(1e-15)) {
+      T x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+      if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) / mc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) / mc; }
+      if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) / ma; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) / ma; }
+      if (x1 > l1) x1 = l1; else if (x1 < -l1) x1 = -l1;
+      for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
+    } else {   // parallel axes: end points of 1 against 2, then of 2 against 1 (<= 2 contacts)
+      single = false;
+      for (int sg = -1; sg <= 1 && h.n < 2; sg += 2) {
+        T e1[3], t[3]; for (int k = 0; k < 3; k++) { e1[k] = p1[k] + a1[k] * sg * l1; t[k] = e1[k] - p2[k]; }
+        T x2 = dot3(t, a2);
+        if (x2 >= -l2 && x2 <= l2) { T e2[3]; for (int k = 0; k < 3; k++) e2[k] = p2[k] + a2[k] * x2; sphere_sphere(h, m, e1, r1, e2, r2); }
+      }
+      for (int sg = -1; sg <= 1 && h.n < 2; sg += 2) {
+        T e2[3], t[3]; for (int k = 0; k < 3; k++) { e2[k] = p2[k] + a2[k] * sg * l2; t[k] = e2[k] - p1[k]; }
+        T x1 = dot3(t, a1);
+        if (x1 >= -l1 && x1 <= l1) { T e1[3]; for (int k = 0; k < 3; k++) e1[k] = p1[k] + a1[k] * x1; sphere_sphere(h, m, e1, r1, e2, r2); }
+      }
+    }
+  }
+  if (single) sphere_sphere(h, m, c1, r1, c2, r2);
+}
+
+// [3P] mj_collision.  Broad phase: every candidate pair of the compile-time table against its bounding spheres, straight-
+// line code on the geom centres (read once from the LDS column) that leaves one bit per pair.  Narrow phase + constraint
+// rows: only for the pairs some lane of the wave kept, in table order (the PGS row order depends on it).
+template <class T>
+REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) {
+  K.ncon = 0;
+  REX_HSTAMP(c0);
+  T gp[NGEOM][3];
+  static_for<1, NGEOM>([&](auto GG) { constexpr int g = GG; for (int k = 0; k < 3; k++) gp[g][k] = dual(s, GEO_GEOM + (g - 1) * 6 + k); });
+  unsigned cand[(MAXPAIR + 31) / 32] = {};
+  static_for<0, kPairs.n>([&](auto PP) {
+    constexpr int p = PP, g1 = kPairs.g1[p], g2 = kPairs.g2[p];
+    bool keep;
+    if constexpr (kGeomType[g1] == G_PLANE) keep = !(gp[g2][2] - m.geom_bound[g2] > m.margin);   // bounding sphere above the floor
+    else {
+      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = m.geom_bound[g1] + m.geom_bound[g2] + m.margin;
+      keep = !(dot3(d, d) > reach * reach);
+    }
+    cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;
+  });
+  REX_HSTAMP(c1); REX_HACC(K, HT_BROAD, c0, c1);
+  // one runtime loop over the pairs and ONE inlined copy of the narrow phase and of the row construction (they are large:
+  // instruction fetch, not arithmetic, is what a second copy costs); the mask words stay in registers
+  constexpr int NW = (kPairs.n + 31) / 32;
+  static_assert(NW == 4, "pair mask words");
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+  for (int p = 0; p < kPairs.n; p++) {
+    const int w = p >> 5;
+    const unsigned cw = w == 0 ? cand[0] : (w == 1 ? cand[1] : (w == 2 ? cand[2] : cand[3]));
+    const bool mine = (cw >> (p & 31)) & 1u;
+    if (!REX_WAVE_ANY(mine)) continue;
+    REX_HSTAMP(n0);
+    const PairRec<T> pr = m.pair[p];   // by value: one 64-byte uniform load
+    Hits<T> h; T yaxis[3]; bool has_y;
+    h.n = 0;
+    if (mine) collide_pair(m, s, pr, h, yaxis, has_y);
+    REX_HSTAMP(n1); REX_HACC(K, HT_PAIR, n0, n1); REX_HCNT(K, HC_PAIR_CALLS, 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int k = 0; k < 2; k++) {
+      if (!REX_WAVE_ANY(k < h.n)) break;
+      // select instead of indexing: the hits stay in registers
+      const T hd = k ? h.dist[1] : h.dist[0];
+      const T hp[3] = {k ? h.pos[1][0] : h.pos[0][0], k ? h.pos[1][1] : h.pos[0][1], k ? h.pos[1][2] : h.pos[0][2]};
+      const T hn[3] = {k ? h.normal[1][0] : h.normal[0][0], k ? h.normal[1][1] : h.normal[0][1], k ? h.normal[1][2] : h.normal[0][2]};
+      REX_HSTAMP(r0);
+      if (k < h.n) add_contact(K, s, m, qvel, pr, hd, hp, hn, has_y ? yaxis : (const T*)nullptr);
+      REX_HSTAMP(r1); REX_HACC(K, HT_ROWS, r0, r1); REX_HCNT(K, HC_ROW_CALLS, 1);
+    }
+  }
+  REX_HSTAMP(c2); REX_HACC(K, HT_NARROW_LOOP, c1, c2);
 }
 
 // [3P] mj_solPGS on the dual, with qacc carried along: res_i = J_i qacc - aref_i + R_i f_i.  Rows stay in scratch: only
@@ -538,7 +634,7 @@ REX_HD void make_constraints(const Model<T>& m, const T* qpos, const T* qvel, Sc
 template <class T>
 REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K, Scratch<T>& s, T* qacc) {
   for (int k = 0; k < NV; k++) qacc[k] = K.qacc_smooth[k];
-  for (int i = 0; i < s.nefc; i++) {
+  for (int i = 0; i < K.nefc; i++) {
     T x[NV], jr[NV];
     for (int k = 0; k < NV; k++) { jr[k] = s.J[i][k]; x[k] = jr[k]; }
     solve(F, x);
@@ -550,7 +646,7 @@ REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K,
   int it = 0;
   for (; it < m.iterations; it++) {
     T improvement = 0;
-    for (int i = 0; i < s.nefc; i++) {
+    for (int i = 0; i < K.nefc; i++) {
       T res = s.R[i] * s.force[i] - s.aref[i];
       for (int k = 0; k < NV; k++) res += s.J[i][k] * qacc[k];
       T old = s.force[i], nf = hmax(T(0), old - res / s.Adiag[i]), df = nf - old;
@@ -563,10 +659,6 @@ REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K,
   return it;
 }
 
-#ifndef REX_STAMP
-#define REX_STAMP(var) ((void)0)
-#define REX_TACC(slot, t0, t1) ((void)0)
-#endif
 // phase boundary: keeps the machine scheduler from interleaving two phases of forward() (which only lengthens live
 // ranges: 739 -> spilled VGPRs without it)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -575,11 +667,6 @@ REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K,
 #define REX_FENCE() ((void)0)
 #endif
 
-#if defined(REX_PGS_FENCE) && defined(__HIP_DEVICE_COMPILE__)
-#define REX_PFENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define REX_PFENCE() ((void)0)
-#endif
 // keeps a batch of LDS reads together: all of them are issued, waited for once and held in registers from here on
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NOPIN)
 #define REX_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
@@ -631,10 +718,10 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
 // sweep costs n^2 LDS reads instead of 2 n nv reads of J / M^-1 J^T rows from scratch (which miss every cache level);
 // J is read once per row pair to build A and once more for qacc = qacc_smooth + M^-1 J^T f.
 template <class T>
-REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K, Scratch<T>& s, T* qacc) {
-  const int n = s.nefc;
+REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, Scratch<T>& s, T* qacc) {
+  const int n = K.nefc;
   T* const col = (T*)__builtin_assume_aligned(&dual(s, 0), 16);
-  REX_PFENCE(); REX_STAMP(p0);
+  REX_HSTAMP(p0);
   static_for<0, DUAL_DI + DUAL_NMAX>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
   for (int j = 0; j < n; j++) {
     T x[NV], jr[NV];
@@ -653,7 +740,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, const Kin<T
     T a = s.R[j]; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
     pa[j] = a; col[DUAL_DI + j] = T(1) / a;
   }
-  REX_PFENCE(); REX_STAMP(p1); REX_TACC(20, p0, p1);
+  REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
   // Sweeps over the smallest of three fixed sizes that holds every lane of the wave.
   int it;
   T f[DUAL_NMAX];
@@ -669,7 +756,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, const Kin<T
       default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
     }
   }
-  REX_PFENCE(); REX_STAMP(p2); REX_TACC(21, p1, p2);
+  REX_HSTAMP(p2); REX_HACC(K, HT_SWEEPS, p1, p2); REX_HCNT(K, HC_SWEEPS, it);
   T x[NV];
   for (int k = 0; k < NV; k++) x[k] = 0;
   static_for<0, DUAL_NMAX>([&](auto II) {
@@ -678,19 +765,17 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, const Kin<T
   });
   solve(F, x);
   for (int k = 0; k < NV; k++) qacc[k] = K.qacc_smooth[k] + x[k];
-  REX_STAMP(p3); REX_TACC(22, p2, p3);
+  REX_HSTAMP(p3); REX_HACC(K, HT_QACC, p2, p3);
   return it;
 }
 
 // [3P] mj_forward
 template <class T>
 REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc) {
-  s.overflow = 0;
-  REX_STAMP(t0);
+  K.overflow = 0;
+  REX_HSTAMP(t0);
   kinematics(m, qpos, K, s);
-  REX_FENCE(); REX_STAMP(t1); REX_TACC(8, t0, t1);
   com_pos(m, L, K, s);
-  REX_FENCE(); REX_STAMP(t2); REX_TACC(9, t1, t2);
   {
     T qfrc_bias[NV];
     com_vel_rne(m, L, qvel, K, qfrc_bias);
@@ -700,29 +785,22 @@ REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* 
     static_for<0, NV>([&](auto II) { constexpr int i = II; K.qfrc_smooth[i] = -L.damping[i] * qvel[i] - qfrc_bias[i] + K.qfrc_actuator[i]; });
     static_for<1, NJNT>([&](auto JJ) { constexpr int j = JJ; K.qfrc_smooth[j + 5] -= m.jnt_stiff[j] * qpos[j + 6]; });   // springref 0
   }
-  REX_FENCE(); REX_STAMP(t3); REX_TACC(11, t2, t3);
-  collide(m, s);
-  REX_FENCE(); REX_STAMP(t4); REX_TACC(12, t3, t4);
-  make_constraints(m, qpos, qvel, s);
-  REX_FENCE(); REX_STAMP(t5); REX_TACC(13, t4, t5);
-  // the mass matrix and its factor are built last so that their 185 registers are live only from here on
+  // M right away: it replaces cinert + cdof (278 values) by 185 in the set that has to survive the collision phase
   MassFactor<T> F;
   crb(m, K, F);
-  REX_FENCE(); REX_STAMP(t6); REX_TACC(10, t5, t6);
+  REX_FENCE(); REX_HSTAMP(t3); REX_HACC(K, HT_SMOOTH, t0, t3);
+  limit_rows(m, qpos, qvel, K, s);
+  REX_HSTAMP(t3b); REX_HACC(K, HT_LIMITS, t3, t3b);
+  collide(m, qvel, K, s);
+  REX_FENCE(); REX_HSTAMP(t5);
   factor(F);
   for (int i = 0; i < NV; i++) K.qacc_smooth[i] = K.qfrc_smooth[i];
   solve(F, K.qacc_smooth);
-  REX_FENCE(); REX_STAMP(t7); REX_TACC(14, t6, t7);
-#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
-  atomicAdd(&g_ktime[24 + (s.nefc < 71 ? s.nefc : 71)], 1ull);
-#endif
-  if (s.nefc == 0) { for (int i = 0; i < NV; i++) qacc[i] = K.qacc_smooth[i]; return 0; }
-  int it = s.nefc <= DUAL_NMAX ? solve_pgs_dual(m, F, K, s, qacc) : solve_pgs(m, F, K, s, qacc);   // the scratch-row variant only for rare pile-ups
-  REX_STAMP(t8); REX_TACC(15, t7, t8); REX_TACC(16, t0, t8);
-#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_ktime[17], 1ull); atomicAdd(&g_ktime[18], (unsigned long long)s.nefc); atomicAdd(&g_ktime[19], (unsigned long long)it);
-    if (REX_WAVE_ANY(s.nefc > DUAL_NMAX)) atomicAdd(&g_ktime[23], 1ull); }
-#endif
+  REX_FENCE(); REX_HSTAMP(t7); REX_HACC(K, HT_FACTOR, t5, t7); REX_HCNT(K, HC_EVALS, 1); REX_HCNT(K, HC_NEFC, K.nefc);
+  int it = 0;
+  if (K.nefc == 0) { for (int i = 0; i < NV; i++) qacc[i] = K.qacc_smooth[i]; }
+  else it = K.nefc <= DUAL_NMAX ? solve_pgs_dual(m, F, K, s, qacc) : solve_pgs(m, F, K, s, qacc);   // the scratch-row variant only for rare pile-ups
+  REX_HSTAMP(t8); REX_HACC(K, HT_FORWARD, t0, t8);
   return it;
 }
 

@@ -193,6 +193,7 @@ inline void build_model(Model<double>& m) {
     m.body_invw[b][0] = (A[0] + A[1] + A[2]) / 3; m.body_invw[b][1] = (A[3] + A[4] + A[5]) / 3;
   }
   delete s; delete K;
+  for (int g = 0; g < NGEOM; g++) m.geom_bound[g] = m.geom_rad[g] + m.geom_half[g];
   // packed pair records for the device loop
   for (int p = 0; p < m.npair; p++) {
     PairRec<double>& r = m.pair[p];
@@ -213,7 +214,9 @@ inline bool check_topology(const Model<double>& m) {
     if (m.body_dofnum[b] > 0) ok = ok && m.body_dofadr[b] == kBodyDofAdr[b];
   }
   for (int j = 1; j < NJNT; j++) ok = ok && m.jnt_dadr[j] == j + 5 && m.jnt_qadr[j] == j + 6;
-  for (int g = 0; g < NGEOM; g++) ok = ok && m.geom_body[g] == kGeomBody[g];
+  for (int g = 0; g < NGEOM; g++) ok = ok && m.geom_body[g] == kGeomBody[g] && m.geom_type[g] == kGeomType[g];
+  ok = ok && m.npair == kPairs.n;
+  for (int p = 0; p < kPairs.n && p < m.npair; p++) ok = ok && m.pair_g1[p] == kPairs.g1[p] && m.pair_g2[p] == kPairs.g2[p];
   for (int u = 0; u < NU; u++) ok = ok && m.act_dof[u] == kActDof[u];
   return ok;
 }
@@ -227,7 +230,7 @@ inline void convert_model(const Model<double>& a, Model<T>& b) {
   CP(body_pos); CP(body_quat); CP(body_ipos); CP(body_inertia); CP(body_mass0); CP(subtreemass_root); CP(body_invw); CP(dof_invw);
   CI(jnt_body); CI(jnt_qadr); CI(jnt_dadr); CP(jnt_pos); CP(jnt_axis); CP(jnt_lo); CP(jnt_hi); CP(jnt_stiff);
   CI(dof_body); CI(dof_parent); CP(dof_armature); CP(dof_damping0);
-  CI(geom_type); CI(geom_body); CP(geom_pos); CP(geom_axis); CP(geom_rad); CP(geom_half);
+  CI(geom_type); CI(geom_body); CP(geom_pos); CP(geom_axis); CP(geom_rad); CP(geom_half); CP(geom_bound);
   CI(npair); CI(pair_g1); CI(pair_g2); CI(pair_dim); CP(pair_mu); CI(act_dof); CP(act_gear); CP(qpos0);
   CP(K); CP(B); CP(dmin); CP(dmax); CP(width); CP(margin); CP(timestep); CP(gravity); CP(meaninertia); CP(tolerance);
   CI(iterations);

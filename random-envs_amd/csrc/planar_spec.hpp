@@ -15,7 +15,7 @@
 #endif
 
 // true if the predicate holds on any active lane of the wave (device); the predicate itself on the host
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_WAVE_ANY_OFF)
 #define REX_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
 #else
 #define REX_WAVE_ANY(x) (x)

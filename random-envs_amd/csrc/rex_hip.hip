@@ -415,6 +415,9 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
   for (int k = 0; k < hum::NU; k++) a[k] = (action + k * B)[i];
   for (int b = 0; b < hum::NBODY; b++) xp[b] = (s.aux + b * B)[i];
   hum::Kin<float> kn; hum::Scratch<float> sc;
+#if defined(REX_KTIME)
+  for (int k = 0; k < HT_SLOTS; k++) kn.tacc[k] = 0;
+#endif
   float r; bool dn;
   rocrand_state_philox4x32_10 st;
   int t = s.t[i] + 1;
@@ -426,11 +429,18 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
     (obs + k * B)[i] = val;
     if (term_obs) (term_obs + k * B)[i] = val;
   });
+#if defined(REX_KTIME)
+  for (int k = 0; k < HT_SLOTS; k++) {   // one flush per wave and kernel: the wave maximum of every accumulator
+    unsigned long long v = kn.tacc[k];
+    for (int off = 32; off > 0; off >>= 1) { unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[8 + k], v);
+  }
+#endif
   bool finite = true;
   for (int k = 0; k < hum::NQ; k++) finite = finite && isfinite(q[k]);
   for (int k = 0; k < hum::NV; k++) finite = finite && isfinite(v[k]);
   if (!finite) { atomicAdd(s.counters + 0, 1ull); dn = true; }     // a diverged lane ends its episode
-  if (sc.overflow) atomicAdd(s.counters + 3, 1ull);
+  if (kn.overflow) atomicAdd(s.counters + 3, 1ull);
   if (fl.endless && finite) dn = false;
   s.t[i] = t;
   bool trunc = fl.time_limit && t >= fl.max_steps && !dn;

@@ -34,7 +34,7 @@ static void run_step(int n, const double* qpos, const double* qvel, const double
     env_step(c->m, L, q, v, a, xp, c->k, c->s, r, d, [&](int k, T val) { obs[(size_t)k * n + i] = double(val); });
     for (int k = 0; k < NQ; k++) qpos_out[(size_t)k * n + i] = double(q[k]);
     for (int k = 0; k < NV; k++) qvel_out[(size_t)k * n + i] = double(v[k]);
-    reward[i] = double(r); done[i] = d; if (overflow) overflow[i] = c->s.overflow;
+    reward[i] = double(r); done[i] = d; if (overflow) overflow[i] = c->k.overflow;
     if (xout) for (int b = 0; b < NBODY; b++) xout[(size_t)b * n + i] = double(xp[b]);
   }
 }
@@ -53,7 +53,7 @@ static void run_forward(const double* qpos, const double* qvel, const double* ct
   for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) M[i * NV + j] = double(F.get(i, j));
   int it = forward(c->m, L, q, v, a, c->k, c->s, acc);
   for (int k = 0; k < NV; k++) qacc[k] = double(acc[k]);
-  info[0] = c->s.ncon; info[1] = c->s.nefc; info[2] = it; info[3] = c->s.overflow;
+  info[0] = c->k.ncon; info[1] = c->k.nefc; info[2] = it; info[3] = c->k.overflow;
 }
 
 extern "C" {
@@ -78,7 +78,7 @@ int hh_forward(int f32, const double* qpos, const double* qvel, const double* ct
 }
 }
 extern "C" int hh_contacts(double* out, int maxn) {   // contacts of the last hh_forward<double>
-  Ctx<double>* c = ctx<double>(); int n = c->s.ncon < maxn ? c->s.ncon : maxn;
+  Ctx<double>* c = ctx<double>(); int n = c->k.ncon < maxn ? c->k.ncon : maxn;
   for (int i = 0; i < n; i++) { out[5 * i] = c->s.cb1[i]; out[5 * i + 1] = c->s.cb2[i]; out[5 * i + 2] = c->s.cdist[i]; out[5 * i + 3] = c->s.cdim[i]; out[5 * i + 4] = c->s.cpos[i][2]; }
   return n;
 }
