@@ -195,15 +195,20 @@ struct Lane {   // randomised part of the model (xi)
   T damping[NV];      // dof_damping
 };
 
-// Static-index per-lane state of one forward evaluation: every access below uses compile-time indices, so the compiler
-// keeps it in registers and spills what has to survive the solver (the observation reads cinert / cvel / xipos /
-// qfrc_actuator of the LAST evaluation, random_humanoid.py:193-204).
+// Smooth-dynamics working set of one evaluation (kinematics -> com -> RNE -> CRB).  Every access uses compile-time
+// indices, so it lives in registers -- and only for that phase: what the observation needs later (cinert, cvel, xipos_x,
+// qfrc_actuator of the LAST evaluation, random_humanoid.py:193-204) is parked in Scratch, not kept live across the solver.
 template <class T>
-struct Kin {
+struct Smooth {
   T xmat[NBODY][9], xipos[NBODY][3];
   T com[3];                       // subtree COM of the root (MuJoCo's reference point)
   T cinert[NBODY][10], cvel[NBODY][6], cdof[NV][6];
-  T qfrc_smooth[NV], qfrc_actuator[NV], qacc_smooth[NV];
+};
+
+// what survives the smooth phase inside one evaluation (registers)
+template <class T>
+struct Kin {
+  T qfrc_smooth[NV], qacc_smooth[NV];
   int ncon, nefc, overflow;       // contacts / constraint rows of this evaluation; overflow: some were dropped (MAXCON / MAXEFC)
 #if defined(REX_KTIME)
   unsigned long long tacc[HT_SLOTS];
@@ -220,6 +225,9 @@ template <class T>
 struct Scratch {   // runtime-indexed per-lane arrays (HIP scratch): contacts and constraint rows
   T cpos[MAXCON][3], cdist[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];   // contact log (written, never read back by the engine)
   T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
+  // parked between phases (plain stores / loads at fixed offsets; keeps them out of the register file while the solver runs)
+  T obs_cinert[NBODY][10], obs_cvel[NBODY][6], obs_xipos_x[NBODY], obs_qfrc_actuator[NV];   // observation inputs
+  T rk_q0[NQ], rk_v0[NV], rk_dq[NV], rk_dv[NV];                                              // RK4 accumulators
   HostColumn<T> col;
 };
 
@@ -248,7 +256,7 @@ struct MassFactor {
 // [3P] mj_kinematics, unrolled over the fixed tree.  Leaves xmat / xipos in K and the runtime-indexed geometry
 // (geom poses, dof anchors / axes) in the lane's LDS column.
 template <class T>
-REX_HD void kinematics(const Model<T>& m, const T* qpos, Kin<T>& K, Scratch<T>& s) {
+REX_HD void kinematics(const Model<T>& m, const T* qpos, Smooth<T>& K, Scratch<T>& s) {
   T xp[NBODY][3], xq[NBODY][4];
   for (int k = 0; k < 3; k++) { xp[0][k] = 0; K.xipos[0][k] = 0; }
   xq[0][0] = 1; xq[0][1] = xq[0][2] = xq[0][3] = 0;
@@ -297,7 +305,7 @@ REX_HD void kinematics(const Model<T>& m, const T* qpos, Kin<T>& K, Scratch<T>& 
 
 // [3P] mj_comPos: reference point, cinert, cdof
 template <class T>
-REX_HD void com_pos(const Model<T>& m, const Lane<T>& L, Kin<T>& K, Scratch<T>& s) {
+REX_HD void com_pos(const Model<T>& m, const Lane<T>& L, Smooth<T>& K, Scratch<T>& s) {
   T sc[3] = {0, 0, 0};
   static_for<1, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 3; k++) sc[k] += L.mass[b] * K.xipos[b][k]; });
   for (int k = 0; k < 3; k++) K.com[k] = sc[k] / m.subtreemass_root;   // compile-time subtree mass (Q4-style staleness)
@@ -329,7 +337,7 @@ REX_HD void com_pos(const Model<T>& m, const Lane<T>& L, Kin<T>& K, Scratch<T>& 
 
 // [3P] mj_crb: composite rigid body -> M (packed tree-sparse lower triangle)
 template <class T>
-REX_HD void crb(const Model<T>& m, const Kin<T>& K, MassFactor<T>& F) {
+REX_HD void crb(const Model<T>& m, const Smooth<T>& K, MassFactor<T>& F) {
   T crbI[NBODY][10];
   static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) crbI[b][k] = K.cinert[b][k]; });
   static_rfor<2, NBODY>([&](auto BB) { constexpr int b = BB, p = kBodyParent[b]; for (int k = 0; k < 10; k++) crbI[p][k] += crbI[b][k]; });
@@ -346,7 +354,7 @@ REX_HD void crb(const Model<T>& m, const Kin<T>& K, MassFactor<T>& F) {
 
 // [3P] mj_comVel + mj_rne (flg_acc = 0): bias forces incl. gravity
 template <class T>
-REX_HD void com_vel_rne(const Model<T>& m, const Lane<T>& L, const T* qvel, Kin<T>& K, T (&qfrc_bias)[NV]) {
+REX_HD void com_vel_rne(const Model<T>& m, const Lane<T>& L, const T* qvel, Smooth<T>& K, T (&qfrc_bias)[NV]) {
   T cacc[NBODY][6], cfrc[NBODY][6], cdofdot[NV][6];
   for (int k = 0; k < 6; k++) { K.cvel[0][k] = 0; cacc[0][k] = 0; cfrc[0][k] = 0; }
   cacc[0][5] = m.gravity;   // -gravity: world accelerates upwards
@@ -774,20 +782,24 @@ template <class T>
 REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc) {
   K.overflow = 0;
   REX_HSTAMP(t0);
-  kinematics(m, qpos, K, s);
-  com_pos(m, L, K, s);
-  {
-    T qfrc_bias[NV];
-    com_vel_rne(m, L, qvel, K, qfrc_bias);
-    static_for<0, NV>([&](auto II) { K.qfrc_actuator[II] = 0; });
-    static_for<0, NU>([&](auto UU) {   // motor u drives hinge kActJoint[u]; ctrlrange +-0.4 (humanoid.xml:6)
-      constexpr int u = UU; T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); K.qfrc_actuator[kActDof[u]] += m.act_gear[u] * c; });
-    static_for<0, NV>([&](auto II) { constexpr int i = II; K.qfrc_smooth[i] = -L.damping[i] * qvel[i] - qfrc_bias[i] + K.qfrc_actuator[i]; });
-    static_for<1, NJNT>([&](auto JJ) { constexpr int j = JJ; K.qfrc_smooth[j + 5] -= m.jnt_stiff[j] * qpos[j + 6]; });   // springref 0
-  }
-  // M right away: it replaces cinert + cdof (278 values) by 185 in the set that has to survive the collision phase
   MassFactor<T> F;
-  crb(m, K, F);
+  {
+    Smooth<T> S;
+    kinematics(m, qpos, S, s);
+    com_pos(m, L, S, s);
+    T qfrc_bias[NV], act[NV];
+    com_vel_rne(m, L, qvel, S, qfrc_bias);
+    static_for<0, NV>([&](auto II) { act[II] = 0; });
+    static_for<0, NU>([&](auto UU) {   // motor u drives dof kActDof[u]; ctrlrange +-0.4 (humanoid.xml:6)
+      constexpr int u = UU; T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); act[kActDof[u]] += m.act_gear[u] * c; });
+    static_for<0, NV>([&](auto II) { constexpr int i = II; K.qfrc_smooth[i] = -L.damping[i] * qvel[i] - qfrc_bias[i] + act[i]; });
+    static_for<1, NJNT>([&](auto JJ) { constexpr int j = JJ; K.qfrc_smooth[j + 5] -= m.jnt_stiff[j] * qpos[j + 6]; });   // springref 0
+    // M right away: 185 values replace cinert + cdof (278) in the set that has to survive the collision phase
+    crb(m, S, F);
+    // observation inputs: stored, not kept
+    static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) s.obs_cinert[b][k] = S.cinert[b][k]; for (int k = 0; k < 6; k++) s.obs_cvel[b][k] = S.cvel[b][k]; s.obs_xipos_x[b] = S.xipos[b][0]; });
+    static_for<0, NV>([&](auto II) { s.obs_qfrc_actuator[II] = act[II]; });
+  }
   REX_FENCE(); REX_HSTAMP(t3); REX_HACC(K, HT_SMOOTH, t0, t3);
   limit_rows(m, qpos, qvel, K, s);
   REX_HSTAMP(t3b); REX_HACC(K, HT_LIMITS, t3, t3b);
@@ -818,26 +830,27 @@ REX_HD void integrate_pos(T* qpos, const T* qvel, T h) {
   for (int k = 0; k < 17; k++) qpos[7 + k] += h * qvel[6 + k];
 }
 
-// One mj_step with RK4 ([3P] mj_RungeKutta, N = 4).  `K` keeps the quantities of the LAST forward
-// evaluation (stage 4), which is what the reference's observation / reward read (random_humanoid.py:161-216).
+// One mj_step with RK4 ([3P] mj_RungeKutta, N = 4).  The stage accumulators are parked in Scratch while forward() runs.
 template <class T>
 REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s) {
   const T h = m.timestep;
-  T q0[NQ], v0[NV], dq[NV], dv[NV], acc[NV];
-  for (int k = 0; k < NQ; k++) q0[k] = qpos[k];
-  for (int k = 0; k < NV; k++) { v0[k] = qvel[k]; dq[k] = 0; dv[k] = 0; }
+  static_for<0, NQ>([&](auto KK) { s.rk_q0[KK] = qpos[KK]; });
+  static_for<0, NV>([&](auto KK) { s.rk_v0[KK] = qvel[KK]; s.rk_dq[KK] = 0; s.rk_dv[KK] = 0; });
   for (int stage = 0; stage < 4; stage++) {
+    T acc[NV];
     forward(m, L, qpos, qvel, ctrl, K, s, acc);
     const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3), c = stage == 2 ? h : T(0.5) * h;
-    for (int k = 0; k < NV; k++) { dq[k] += w * qvel[k]; dv[k] += w * acc[k]; }
+    T dq[NV], dv[NV];
+    static_for<0, NV>([&](auto KK) { constexpr int k = KK; dq[k] = s.rk_dq[k] + w * qvel[k]; dv[k] = s.rk_dv[k] + w * acc[k]; });
     if (stage < 3) {
+      static_for<0, NV>([&](auto KK) { constexpr int k = KK; s.rk_dq[k] = dq[k]; s.rk_dv[k] = dv[k]; });
       T vs[NV]; for (int k = 0; k < NV; k++) vs[k] = qvel[k];
-      for (int k = 0; k < NQ; k++) qpos[k] = q0[k];
+      static_for<0, NQ>([&](auto KK) { qpos[KK] = s.rk_q0[KK]; });
       integrate_pos(qpos, vs, c);
-      for (int k = 0; k < NV; k++) qvel[k] = v0[k] + c * acc[k];
+      static_for<0, NV>([&](auto KK) { constexpr int k = KK; qvel[k] = s.rk_v0[k] + c * acc[k]; });
     } else {
-      for (int k = 0; k < NQ; k++) qpos[k] = q0[k];
-      for (int k = 0; k < NV; k++) qvel[k] = v0[k] + h * dv[k];
+      static_for<0, NQ>([&](auto KK) { qpos[KK] = s.rk_q0[KK]; });
+      static_for<0, NV>([&](auto KK) { constexpr int k = KK; qvel[k] = s.rk_v0[k] + h * dv[k]; });
       integrate_pos(qpos, dq, h);
     }
   }
@@ -845,12 +858,12 @@ REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const
 
 // _get_obs (random_humanoid.py:193-204): qpos[2:], qvel, cinert, cvel, qfrc_actuator, cfrc_ext (= 0)
 template <class T, class ObsSink>
-REX_HD void emit_obs(const T* qpos, const T* qvel, const Kin<T>& K, ObsSink&& obs) {
+REX_HD void emit_obs(const T* qpos, const T* qvel, const Scratch<T>& s, ObsSink&& obs) {
   static_for<2, NQ>([&](auto KK) { constexpr int k = KK; obs(k - 2, qpos[k]); });
   static_for<0, NV>([&](auto KK) { constexpr int k = KK; obs(22 + k, qvel[k]); });
-  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; static_for<0, 10>([&](auto KK) { constexpr int k = KK; obs(45 + 10 * b + k, K.cinert[b][k]); }); });
-  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; static_for<0, 6>([&](auto KK) { constexpr int k = KK; obs(185 + 6 * b + k, K.cvel[b][k]); }); });
-  static_for<0, NV>([&](auto KK) { constexpr int k = KK; obs(269 + k, K.qfrc_actuator[k]); });
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; static_for<0, 10>([&](auto KK) { constexpr int k = KK; obs(45 + 10 * b + k, s.obs_cinert[b][k]); }); });
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; static_for<0, 6>([&](auto KK) { constexpr int k = KK; obs(185 + 6 * b + k, s.obs_cvel[b][k]); }); });
+  static_for<0, NV>([&](auto KK) { constexpr int k = KK; obs(269 + k, s.obs_qfrc_actuator[k]); });
   for (int k = 0; k < 84; k++) obs(292 + k, T(0));
 }
 
@@ -865,11 +878,11 @@ REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, cons
   for (int b = 0; b < NBODY; b++) { mt += L.mass[b]; s0 += L.mass[b] * xipos_x[b]; }
   for (int u = 0; u < NU; u++) asq += action[u] * action[u];       // data.ctrl holds the raw action (:167)
   for (int f = 0; f < 5; f++) substep(m, L, qpos, qvel, action, K, s);   // frame_skip 5 (:41)
-  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = K.xipos[b][0]; s1 += L.mass[b] * K.xipos[b][0]; });
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = s.obs_xipos_x[b]; s1 += L.mass[b] * xipos_x[b]; });
   const T dt = m.timestep * T(5);
   reward = T(1.25) * (s1 / mt - s0 / mt) / dt - T(0.1) * asq - T(0) /* cfrc_ext = 0, SURVEY Q15 */ + T(5);
   done = (qpos[2] < T(1.0)) || (qpos[2] > T(2.0));                 // :173
-  emit_obs(qpos, qvel, K, obs);
+  emit_obs(qpos, qvel, s, obs);
 }
 
 // observation right after set_state / reset: sim.forward() at the given state (jinja_mujoco_env.py:146-154)
@@ -878,8 +891,8 @@ REX_HD void env_reset_obs(const Model<T>& m, const Lane<T>& L, const T* qpos, co
   T ctrl[NU], acc[NV];
   for (int u = 0; u < NU; u++) ctrl[u] = 0;                        // sim.reset() zeroes data.ctrl
   forward(m, L, qpos, qvel, ctrl, K, s, acc);
-  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = K.xipos[b][0]; });
-  emit_obs(qpos, qvel, K, obs);
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = s.obs_xipos_x[b]; });
+  emit_obs(qpos, qvel, s, obs);
 }
 
 }  // namespace hum

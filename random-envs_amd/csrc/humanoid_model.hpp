@@ -170,7 +170,7 @@ inline void build_model(Model<double>& m) {
   Lane<double> L; L.mass[0] = 0; for (int b = 1; b < NBODY; b++) L.mass[b] = m.body_mass0[b];
   for (int d = 0; d < NV; d++) L.damping[d] = m.dof_damping0[d];
   Scratch<double>* s = new Scratch<double>();
-  Kin<double>* K = new Kin<double>();
+  Smooth<double>* K = new Smooth<double>();
   kinematics(m, m.qpos0, *K, *s); com_pos(m, L, *K, *s);
   MassFactor<double> F; crb(m, *K, F);
   double tr = 0; for (int d = 0; d < NV; d++) tr += F.get(d, d);

@@ -48,9 +48,9 @@ static void run_forward(const double* qpos, const double* qvel, const double* ct
   for (int k = 0; k < NV; k++) v[k] = T(qvel[k]);
   for (int k = 0; k < NU; k++) a[k] = T(ctrl[k]);
   // M before factorisation
-  kinematics(c->m, q, c->k, c->s); com_pos(c->m, L, c->k, c->s);
-  MassFactor<T> F; crb(c->m, c->k, F);
-  for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) M[i * NV + j] = double(F.get(i, j));
+  { Smooth<T> S; kinematics(c->m, q, S, c->s); com_pos(c->m, L, S, c->s);
+    MassFactor<T> F; crb(c->m, S, F);
+    for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) M[i * NV + j] = double(F.get(i, j)); }
   int it = forward(c->m, L, q, v, a, c->k, c->s, acc);
   for (int k = 0; k < NV; k++) qacc[k] = double(acc[k]);
   info[0] = c->k.ncon; info[1] = c->k.nefc; info[2] = it; info[3] = c->k.overflow;
