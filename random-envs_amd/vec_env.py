@@ -264,7 +264,7 @@ class VecRandomEnv(DRConfig):
     def counters(self):
         out = (ctypes.c_int64 * 4)()
         _native.check(self._L.rex_get_counters(self._h, out))
-        return dict(nonfinite=out[0], gaussian_fail=out[1], solver_capped=out[2])
+        return dict(nonfinite=out[0], gaussian_fail=out[1], solver_capped=out[2], overflow=out[3])
 
     def enable_timing(self, flag=True):
         _native.check(self._L.rex_enable_timing(self._h, int(flag)))

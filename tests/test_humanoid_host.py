@@ -81,6 +81,29 @@ def test_forward_dynamics_fp64(hh):
     assert worst < 1e-9 and ncon_seen > 50
 
 
+def test_forward_dynamics_pile_ups(hh):
+    """Row counts across the solver's three paths: <= 16 rows, 17..21 rows (largest in-LDS sweep size) and > 21 rows
+    (scratch-row fallback): a humanoid lying / crouching on the floor with joints past their limits."""
+    O = lib(); rng = np.random.RandomState(5)
+    nom = np.array(SPECS["humanoid"].nominal_task); seen = {"le16": 0, "17_21": 0, "gt21": 0}; worst = 0
+    for k in range(160):
+        q = np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float)
+        q[7:] += rng.uniform(-1.2, 1.2, 17)                               # many hinges beyond their range -> limit rows
+        q[2] = rng.uniform(0.05, 0.6)                                     # low: torso / limbs on the floor
+        qq = np.array([1, 0, 0, 0]) + rng.uniform(-1, 1, 4); q[3:7] = qq / np.linalg.norm(qq)
+        v = rng.uniform(-1, 1, 23); a = rng.uniform(-.4, .4, 17); xi = nom * rng.uniform(.9, 1.1, 30)
+        qa_o = np.zeros(23); M_o = np.zeros((23, 23)); nc, ne, it = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        O.mjo_humanoid_probe(_p(q), _p(v), _p(a), _p(xi), None, _p(qa_o), _p(M_o), ctypes.byref(nc), ctypes.byref(ne), ctypes.byref(it), None, None, 0)
+        qa_h = np.zeros(23); M_h = np.zeros((23, 23)); info = np.zeros(4, dtype=np.int32)
+        hh.hh_forward(0, _p(q), _p(v), _p(a), _p(xi), _p(qa_h), _p(M_h), info.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        if info[3] or ne.value > 64: continue                               # dropped rows (MAXCON / MAXEFC): not comparable
+        assert info[0] == nc.value and info[1] == ne.value, (k, info, nc.value, ne.value)
+        seen["le16" if ne.value <= 16 else ("17_21" if ne.value <= 21 else "gt21")] += 1
+        worst = max(worst, np.abs(qa_o - qa_h).max() / (1 + np.abs(qa_o).max()))
+    assert min(seen.values()) >= 3, seen
+    assert worst < 1e-8, worst
+
+
 def test_env_step_obs_reward(hh):
     n = 200
     q, v, a, xi = _states(n, 1)
