@@ -15,7 +15,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if "planar" in k or "cartpole" in k:
+            if "planar" in k or "cartpole" in k or "humanoid" in k:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 out.setdefault(k, {}).setdefault("_regs", {"VGPR": r.get("VGPR_Count"), "AGPR": r.get("Accum_VGPR_Count"),
                                                            "SGPR": r.get("SGPR_Count"), "scratch": r.get("Scratch_Size"),
@@ -31,6 +31,9 @@ for k, v in out.items():
         v["hbm_bytes_per_launch"] = {"fetch_raw": f, "fetch_x2_gfx950": 2 * f, "write": w, "total_corrected": 2 * f + w}
 json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1)
 step = [k for k in out if "planar_step_kernel" in k]
+for extra in ("bench.log", "phases.log"):   # humanoid runs (collect_humanoid.sh)
+    if os.path.exists(os.path.join(P, extra)):
+        shutil.copy(os.path.join(P, extra), os.path.join(ROOT, "profiles", tag + "_" + extra))
 if step and "hbm_bytes_per_launch" in out[step[0]]:
     json.dump({"kernel": step[0], "bytes_per_launch": out[step[0]]["hbm_bytes_per_launch"]["total_corrected"],
                "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag},
