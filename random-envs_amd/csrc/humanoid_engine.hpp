@@ -591,12 +591,16 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
   T gp[NGEOM][3];
   static_for<1, NGEOM>([&](auto GG) { constexpr int g = GG; for (int k = 0; k < 3; k++) gp[g][k] = dual(s, GEO_GEOM + (g - 1) * 6 + k); });
   unsigned cand[(MAXPAIR + 31) / 32] = {};
+  // the 109 thresholds (bound1 + bound2 + margin)^2 are constants of the model: left alone, LICM hoists them out of the RK4 /
+  // frame-skip loops and the register allocator then reloads each one from scratch right before its compare (109 dependent
+  // ~500-cycle round trips per evaluation were measured).  An opaque margin keeps them two adds and a multiply at the use.
+  T margin = m.margin; opaque(margin);
   static_for<0, kPairs.n>([&](auto PP) {
     constexpr int p = PP, g1 = kPairs.g1[p], g2 = kPairs.g2[p];
     bool keep;
-    if constexpr (kGeomType[g1] == G_PLANE) keep = !(gp[g2][2] - m.geom_bound[g2] > m.margin);   // bounding sphere above the floor
+    if constexpr (kGeomType[g1] == G_PLANE) keep = !(gp[g2][2] - m.geom_bound[g2] > margin);   // bounding sphere above the floor
     else {
-      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = m.geom_bound[g1] + m.geom_bound[g2] + m.margin;
+      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = m.geom_bound[g1] + m.geom_bound[g2] + margin;
       keep = !(dot3(d, d) > reach * reach);
     }
     cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;

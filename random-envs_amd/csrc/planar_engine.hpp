@@ -38,18 +38,6 @@ REX_HD double abs_t(double a) { return fabs(a); }
 template <class T> REX_HD T min_t(T a, T b) { return a < b ? a : b; }
 template <class T> REX_HD T max_t(T a, T b) { return a > b ? a : b; }
 
-// Optimisation barrier: tells the compiler the value may have changed.  Used at the top of the
-// solver loops so that LLVM's loop-invariant code motion does not hoist every lever arm and
-// Jacobian entry of every contact slot out of the loops (it does, speculatively, and the ~200
-// hoisted values then spill to scratch memory: 590 MB of HBM writes per launch were measured).
-template <class T> REX_HD void opaque(T& x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(x));
-#else
-  (void)x;
-#endif
-}
-
 // fast reciprocal / division: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE sequence.
 // The parity tolerance (1e-4 relative on qvel) is four orders above its error.
 REX_HD float rcp_t(float a) {

@@ -23,6 +23,19 @@
 
 namespace rex {
 
+// Optimisation barrier: tells the compiler the value may have changed.  Used at the top of the
+// solver loops so that LLVM's loop-invariant code motion does not hoist every lever arm and
+// Jacobian entry of every contact slot out of the loops (it does, speculatively, and the ~200
+// hoisted values then spill to scratch memory: 590 MB of HBM writes per launch were measured).
+template <class T> REX_HD void opaque(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#else
+  (void)x;
+#endif
+}
+
+
 template <int N>
 struct IC { static constexpr int value = N; constexpr operator int() const { return N; } };
 
