@@ -593,14 +593,15 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
   unsigned cand[(MAXPAIR + 31) / 32] = {};
   // the 109 thresholds (bound1 + bound2 + margin)^2 are constants of the model: left alone, LICM hoists them out of the RK4 /
   // frame-skip loops and the register allocator then reloads each one from scratch right before its compare (109 dependent
-  // ~500-cycle round trips per evaluation were measured).  An opaque margin keeps them two adds and a multiply at the use.
-  T margin = m.margin; opaque(margin);
+  // ~500-cycle round trips per evaluation were measured).  Opaque copies of the margin and the 17 bounds keep them two adds and a multiply at the use.
+  T margin = m.margin, bnd[NGEOM]; opaque(margin);
+  static_for<1, NGEOM>([&](auto GG) { constexpr int g = GG; bnd[g] = m.geom_bound[g]; opaque(bnd[g]); });
   static_for<0, kPairs.n>([&](auto PP) {
     constexpr int p = PP, g1 = kPairs.g1[p], g2 = kPairs.g2[p];
     bool keep;
-    if constexpr (kGeomType[g1] == G_PLANE) keep = !(gp[g2][2] - m.geom_bound[g2] > margin);   // bounding sphere above the floor
+    if constexpr (kGeomType[g1] == G_PLANE) keep = !(gp[g2][2] - bnd[g2] > margin);   // bounding sphere above the floor
     else {
-      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = m.geom_bound[g1] + m.geom_bound[g2] + margin;
+      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = bnd[g1] + bnd[g2] + margin;
       keep = !(dot3(d, d) > reach * reach);
     }
     cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;
@@ -695,30 +696,44 @@ REX_HD void pin_all(T (&a)[NP]) { if constexpr (Q < NP) { REX_PIN4(a[Q], a[Q + 1
 // live in registers and every index is a compile-time constant: a row update is one batch of LDS reads at fixed offsets
 // (no address arithmetic, no LDS write) followed by four short FMA chains.  Rows beyond the largest row count of the wave
 // are skipped; padding inside the range is zero, which makes its update a no-op.
+template <int NC, int I, class T>
+REX_HD void pgs_load_row(const T* col, T (&a)[(NC + 3) / 4 * 4 + 2]) {   // row I of the packed A, then b_I and 1 / A_II
+  constexpr int NP = (NC + 3) / 4 * 4;
+  static_for<0, NP>([&](auto JJ) { constexpr int j = JJ; a[j] = j < NC ? col[j <= I ? tri(I) + j : tri(j) + I] : T(0); });
+  a[NP] = col[DUAL_B + I]; a[NP + 1] = col[DUAL_DI + I];
+}
+template <int Q, int N, class T>
+REX_HD void pin_row(T (&a)[N]) {
+  if constexpr (Q + 4 <= N) { REX_PIN4(a[Q], a[Q + 1], a[Q + 2], a[Q + 3]); pin_row<Q + 4>(a); }
+  else if constexpr (Q + 2 <= N) { REX_PIN2(a[Q], a[Q + 1]); pin_row<Q + 2>(a); }
+}
+
 template <int NC, class T>
 REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX]) {
   constexpr int NP = (NC + 3) / 4 * 4;
   const T scale = T(1) / (m.meaninertia * T(NV));
+  // Software pipeline over the rows: the reads of row i + 1 (they do not depend on the forces) are issued before row i is
+  // consumed, so the LDS latency hides behind the FMA chains and the projection of the previous row.  All NC rows run (no
+  // branch between rows: the whole sweep is one basic block); rows >= n are zero padding and leave f unchanged.
+  T buf[NP + 2];
+  pgs_load_row<NC, 0>(col, buf);
   int it = 0;
   for (; it < m.iterations; it++) {
     T improvement = 0;
     static_for<0, NC>([&](auto II) {
-      constexpr int i = II;
-      if (REX_WAVE_ANY(i < n)) {
-        T a[NP];
-        static_for<0, NP>([&](auto JJ) { constexpr int j = JJ; a[j] = j < NC ? col[j <= i ? tri(i) + j : tri(j) + i] : T(0); });
-        T bi = col[DUAL_B + i], di = col[DUAL_DI + i];
-        pin_all<0>(a);
-        REX_PIN2(bi, di);
-        T r0 = bi, r1 = 0, r2 = 0, r3 = 0;
-        static_for<0, NP / 4>([&](auto QQ) {
-          constexpr int q = 4 * QQ;
-          r0 += a[q] * f[q]; if constexpr (q + 1 < NC) r1 += a[q + 1] * f[q + 1]; if constexpr (q + 2 < NC) r2 += a[q + 2] * f[q + 2]; if constexpr (q + 3 < NC) r3 += a[q + 3] * f[q + 3];
-        });
-        const T res = (r0 + r1) + (r2 + r3), old = f[i], nf = hmax(T(0), old - res * di), df = nf - old;
-        f[i] = nf;
-        improvement -= T(0.5) * df * df * a[i] + df * res;
-      }
+      constexpr int i = II, nxt = (i + 1) % NC;
+      T a[NP + 2];
+      static_for<0, NP + 2>([&](auto KK) { a[KK] = buf[KK]; });
+      pgs_load_row<NC, nxt>(col, buf);   // next row (row 0 of the next sweep after the last one): in flight while this one is used
+      pin_row<0>(a);
+      T r0 = a[NP], r1 = 0, r2 = 0, r3 = 0;
+      static_for<0, NP / 4>([&](auto QQ) {
+        constexpr int q = 4 * QQ;
+        r0 += a[q] * f[q]; if constexpr (q + 1 < NC) r1 += a[q + 1] * f[q + 1]; if constexpr (q + 2 < NC) r2 += a[q + 2] * f[q + 2]; if constexpr (q + 3 < NC) r3 += a[q + 3] * f[q + 3];
+      });
+      const T res = (r0 + r1) + (r2 + r3), old = f[i], nf = hmax(T(0), old - res * a[NP + 1]), df = nf - old;
+      f[i] = nf;
+      improvement -= T(0.5) * df * df * a[i] + df * res;
     });
     if (improvement * scale < m.tolerance) { it++; break; }
   }
@@ -753,18 +768,20 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
     pa[j] = a; col[DUAL_DI + j] = T(1) / a;
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
-  // Sweeps over the smallest of three fixed sizes that holds every lane of the wave.
+  // Sweeps over the smallest of five fixed sizes that holds every lane of the wave.
   int it;
   T f[DUAL_NMAX];
   static_for<0, DUAL_NMAX>([&](auto II) { f[II] = T(0); });
   {
-    int lvl = REX_WAVE_ANY(n > 16) ? 2 : (REX_WAVE_ANY(n > 8) ? 1 : 0);
+    int lvl = REX_WAVE_ANY(n > 16) ? 4 : (REX_WAVE_ANY(n > 12) ? 3 : (REX_WAVE_ANY(n > 8) ? 2 : (REX_WAVE_ANY(n > 4) ? 1 : 0)));
 #if defined(__HIP_DEVICE_COMPILE__)
     lvl = __builtin_amdgcn_readfirstlane(lvl);
 #endif
     switch (lvl) {
-      case 0: it = pgs_sweeps<8>(m, col, n, f); break;
-      case 1: it = pgs_sweeps<16>(m, col, n, f); break;
+      case 0: it = pgs_sweeps<4>(m, col, n, f); break;
+      case 1: it = pgs_sweeps<8>(m, col, n, f); break;
+      case 2: it = pgs_sweeps<12>(m, col, n, f); break;
+      case 3: it = pgs_sweeps<16>(m, col, n, f); break;
       default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
     }
   }
