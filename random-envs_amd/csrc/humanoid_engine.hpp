@@ -155,7 +155,7 @@ template <class T> REX_HD void qmul(T* r, const T* a, const T* b) {
 }
 template <class T> REX_HD void qnorm(T* q) {
   T n = hsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < T(1e-15)) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { T i = T(1) / n; q[0] *= i; q[1] *= i; q[2] *= i; q[3] *= i; }
+  if (n < T(1e-15)) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { T i = rcp_t(n); q[0] *= i; q[1] *= i; q[2] *= i; q[3] *= i; }
 }
 template <class T> REX_HD void q2mat(T* m, const T* q) {
   T w = q[0], x = q[1], y = q[2], z = q[3];
@@ -384,7 +384,7 @@ template <class T>
 REX_HD void factor(MassFactor<T>& F) {
   static_rfor<0, NV>([&](auto KK) {
     constexpr int k = KK;
-    const T inv = T(1) / F.a[midx(k, k)];
+    const T inv = rcp_t(F.a[midx(k, k)]);
     for_anc<k>([&](auto II) {
       constexpr int i = II;
       const T a = F.a[midx(k, i)] * inv;
@@ -404,16 +404,16 @@ REX_HD void solve(const MassFactor<T>& F, T (&x)[NV]) {
 // ---- collision ([3P] engine_collision_primitive) -----------------------------------------------------
 template <class T>
 REX_HD void make_frame(T* f) {   // [3P] mju_makeFrame
-  T n = hsqrt(dot3(f, f)); for (int k = 0; k < 3; k++) f[k] /= n;
+  const T in = rcp_t(hsqrt(dot3(f, f))); for (int k = 0; k < 3; k++) f[k] *= in;
   if (hsqrt(dot3(f + 3, f + 3)) < T(0.5)) { f[3] = f[4] = f[5] = 0; if (f[1] < T(0.5) && f[1] > T(-0.5)) f[4] = 1; else f[5] = 1; }
   T d = dot3(f, f + 3); for (int k = 0; k < 3; k++) f[3 + k] -= d * f[k];
   T n2 = hsqrt(dot3(f + 3, f + 3));
-  if (n2 < T(1e-15)) { f[3] = 1; f[4] = 0; f[5] = 0; } else for (int k = 0; k < 3; k++) f[3 + k] /= n2;
+  if (n2 < T(1e-15)) { f[3] = 1; f[4] = 0; f[5] = 0; } else { const T in2 = rcp_t(n2); for (int k = 0; k < 3; k++) f[3 + k] *= in2; }
   cross3(f + 6, f, f + 3);
 }
 template <class T>
 REX_HD T impedance3(const Model<T>& m, T x_abs) {   // power 2, midpoint .5
-  T x = x_abs / m.width;
+  T x = x_abs * rcp_t(m.width);
   T y = x < T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
   T imp = m.dmin + y * (m.dmax - m.dmin);
   return x >= T(1) ? m.dmax : imp;
@@ -455,7 +455,7 @@ REX_HD void limit_rows(const Model<T>& m, const T* qpos, const T* qvel, Kin<T>& 
       if (dist < T(0) && ne < MAXEFC) {
         for (int k = 0; k < NV; k++) s.J[ne][k] = (k == d) ? T(-side) : T(0);
         T imp = impedance3(m, habs(dist));
-        s.R[ne] = hmax(T(1e-15), (T(1) - imp) * m.dof_invw[d] / imp);
+        s.R[ne] = hmax(T(1e-15), (T(1) - imp) * m.dof_invw[d] * rcp_t(imp));
         s.aref[ne] = -m.B * (T(-side) * qvel[d]) - m.K * imp * dist;
         ne++;
       }
@@ -485,14 +485,14 @@ REX_HD void add_contact(Kin<T>& K, Scratch<T>& s, const Model<T>& m, const T* qv
     T jn[1][NV];
     jac_dirs<1>(s, pr.mask1, pr.mask2, pos, f, jn);
     T vel = 0; for (int k = 0; k < NV; k++) { s.J[ne][k] = jn[0][k]; vel += jn[0][k] * qvel[k]; }
-    s.R[ne] = hmax(T(1e-15), (T(1) - imp) * tran / imp);
+    s.R[ne] = hmax(T(1e-15), (T(1) - imp) * tran * rcp_t(imp));
     s.aref[ne] = -m.B * vel - kterm;
     ne++;
   } else {
     if (ne + 4 > MAXEFC) { K.overflow = 1; return; }
     T jf[3][NV];
     jac_dirs<3>(s, pr.mask1, pr.mask2, pos, f, jf);
-    const T R1 = hmax(T(1e-15), (T(1) - imp) * (tran + mu * mu * tran) / imp), Rpy = T(2) * mu * mu * R1;
+    const T R1 = hmax(T(1e-15), (T(1) - imp) * (tran + mu * mu * tran) * rcp_t(imp)), Rpy = T(2) * mu * mu * R1;
     for (int t = 1; t <= 2; t++) {
       for (int sg = 1; sg >= -1; sg -= 2) {
         T vel = 0;
@@ -514,7 +514,7 @@ REX_HD void sphere_sphere(Hits<T>& h, const Model<T>& m, const T* c1, T r1, cons
   T len = hsqrt(dot3(d, d)), dist = len - r1 - r2;
   if (dist > m.margin || h.n >= 2) return;
   T n[3] = {1, 0, 0};
-  if (len >= T(1e-15)) { n[0] = d[0] / len; n[1] = d[1] / len; n[2] = d[2] / len; }
+  if (len >= T(1e-15)) { const T il = rcp_t(len); n[0] = d[0] * il; n[1] = d[1] * il; n[2] = d[2] * il; }
   const bool first = h.n == 0; h.n++;
   for (int x = 0; x < 3; x++) { const T px = c1[x] + n[x] * (r1 + T(0.5) * dist); if (first) { h.pos[0][x] = px; h.normal[0][x] = n[x]; } else { h.pos[1][x] = px; h.normal[1][x] = n[x]; } }
   if (first) h.dist[0] = dist; else h.dist[1] = dist;
@@ -559,9 +559,10 @@ REX_HD void collide_pair(const Model<T>& m, Scratch<T>& s, const PairRec<T>& pr,
     T dif[3] = {-d[0], -d[1], -d[2]};   // p1 - p2
     T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = ma * mc - mb * mb;
     if (habs(det) >= T(1e-15)) {
-      T x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-      if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) / mc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) / mc; }
-      if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) / ma; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) / ma; }
+      const T idet = rcp_t(det), imc = rcp_t(mc), ima = rcp_t(ma);
+      T x1 = (mc * u - mb * v) * idet, x2 = (ma * v - mb * u) * idet;
+      if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) * imc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) * imc; }
+      if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) * ima; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) * ima; }
       if (x1 > l1) x1 = l1; else if (x1 < -l1) x1 = -l1;
       for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
     } else {   // parallel axes: end points of 1 against 2, then of 2 against 1 (<= 2 contacts)
@@ -765,7 +766,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
     }
     if (i < j) { T a0 = 0; for (int k = 0; k < NV; k++) a0 += s.J[i][k] * x[k]; pa[i] = a0; }
     T a = s.R[j]; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
-    pa[j] = a; col[DUAL_DI + j] = T(1) / a;
+    pa[j] = a; col[DUAL_DI + j] = rcp_t(a);
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
   // Sweeps over the smallest of five fixed sizes that holds every lane of the wave.
@@ -844,7 +845,8 @@ REX_HD void integrate_pos(T* qpos, const T* qvel, T h) {
   T w[3] = {qvel[3], qvel[4], qvel[5]}, n = hsqrt(dot3(w, w));
   if (n * h > T(1e-15)) {
     T sn, cs; hsincos(T(0.5) * n * h, sn, cs);
-    T dq[4] = {cs, w[0] / n * sn, w[1] / n * sn, w[2] / n * sn}, r[4];
+    const T sn_n = sn * rcp_t(n);
+    T dq[4] = {cs, w[0] * sn_n, w[1] * sn_n, w[2] * sn_n}, r[4];
     qmul(r, qpos + 3, dq); qnorm(r);
     for (int k = 0; k < 4; k++) qpos[3 + k] = r[k];
   }

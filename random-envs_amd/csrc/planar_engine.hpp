@@ -38,17 +38,6 @@ REX_HD double abs_t(double a) { return fabs(a); }
 template <class T> REX_HD T min_t(T a, T b) { return a < b ? a : b; }
 template <class T> REX_HD T max_t(T a, T b) { return a > b ? a : b; }
 
-// fast reciprocal / division: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE sequence.
-// The parity tolerance (1e-4 relative on qvel) is four orders above its error.
-REX_HD float rcp_t(float a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_rcpf(a);
-#else
-  return 1.0f / a;
-#endif
-}
-REX_HD double rcp_t(double a) { return 1.0 / a; }
-
 // per-lane dynamic parameters (the randomised part of the model)
 template <class T, class S>
 struct LaneParams {

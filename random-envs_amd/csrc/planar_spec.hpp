@@ -23,6 +23,17 @@
 
 namespace rex {
 
+// fast reciprocal / division: v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE sequence.
+// The parity tolerance (1e-4 relative on qvel) is four orders above its error.
+REX_HD float rcp_t(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(a);
+#else
+  return 1.0f / a;
+#endif
+}
+REX_HD double rcp_t(double a) { return 1.0 / a; }
+
 // Optimisation barrier: tells the compiler the value may have changed.  Used at the top of the
 // solver loops so that LLVM's loop-invariant code motion does not hoist every lever arm and
 // Jacobian entry of every contact slot out of the loops (it does, speculatively, and the ~200
