@@ -243,7 +243,8 @@ template <class T> REX_HD T& dual(Scratch<T>& s, int k) { return s.col.w[k]; }
 #endif
 constexpr int GEO_GEOM = 0;                        // (g - 1) * 6 + {pos 0..2, axis 3..5}, g = 1..17
 constexpr int GEO_DOF = (NGEOM - 1) * 6;           // i * 6 + {anchor 0..2, axis 3..5}, i = 0..22
-static_assert(GEO_DOF + NV * 6 <= DUAL_WORDS, "geometry overlay must fit the LDS column");
+constexpr int HITQ_BASE = GEO_DOF + NV * 6, HITQ_WORDS = 8, HITQ_MAX = 6;   // queued narrow-phase hits: dist, pos, normal, pair index
+static_assert(HITQ_BASE + HITQ_WORDS * HITQ_MAX <= DUAL_WORDS, "geometry overlay + hit queue must fit the LDS column");
 
 // Tree-sparse joint-space inertia, packed (midx).  After factor(): L^T D L in place with the diagonal holding 1/D.
 // Every index into it is a compile-time constant, so on the device it lives in registers (AGPRs as overflow).
@@ -608,6 +609,7 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
     cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;
   });
   REX_HSTAMP(c1); REX_HACC(K, HT_BROAD, c0, c1);
+#if defined(REX_UNION_NARROW)
   // one runtime loop over the pairs and ONE inlined copy of the narrow phase and of the row construction (they are large:
   // instruction fetch, not arithmetic, is what a second copy costs); the mask words stay in registers
   constexpr int NW = (kPairs.n + 31) / 32;
@@ -641,6 +643,58 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
     }
   }
   REX_HSTAMP(c2); REX_HACC(K, HT_NARROW_LOOP, c1, c2);
+#else
+  // Narrow phase per LANE, not per pair: every lane walks its own candidate bits in table order (the PGS row order depends on
+  // it) with its own pair record, so a wave needs as many trips as its busiest lane has candidates (~10) instead of one per
+  // pair of the union over its lanes (~42).  Hits are queued in the free tail of the LDS column and turned into rows slot by
+  // slot afterwards -- again one trip per queue slot, not per contact of the union -- by the ONE inlined copy of add_contact.
+  unsigned w0 = cand[0], w1 = cand[1], w2 = cand[2], w3 = cand[3];
+  static_assert((kPairs.n + 31) / 32 == 4, "pair mask words");
+  T* const col = &dual(s, 0);
+  int nq = 0;
+  bool more = true;
+  while (more) {
+    for (;;) {   // gather: lanes with candidates left and room for two more hits
+      const bool go = ((w0 | w1 | w2 | w3) != 0u) && nq <= HITQ_MAX - 2;
+      if (!REX_WAVE_ANY(go)) break;
+      REX_HSTAMP(n0);
+      if (go) {
+        const unsigned wsel = w0 ? w0 : (w1 ? w1 : (w2 ? w2 : w3));
+        const int base = w0 ? 0 : (w1 ? 32 : (w2 ? 64 : 96));
+        const int p = base + __builtin_ctz(wsel);
+        const unsigned cleared = wsel & (wsel - 1u);
+        if (w0) w0 = cleared; else if (w1) w1 = cleared; else if (w2) w2 = cleared; else w3 = cleared;
+        const PairRec<T> pr = m.pair[p];   // per-lane gather from the constant table
+        Hits<T> h; T yaxis[3]; bool has_y;
+        collide_pair(m, s, pr, h, yaxis, has_y);
+        if (h.n > 0) { T* q = col + HITQ_BASE + HITQ_WORDS * nq; q[0] = h.dist[0]; for (int k = 0; k < 3; k++) { q[1 + k] = h.pos[0][k]; q[4 + k] = h.normal[0][k]; } q[7] = T(p); nq++; }
+        if (h.n > 1) { T* q = col + HITQ_BASE + HITQ_WORDS * nq; q[0] = h.dist[1]; for (int k = 0; k < 3; k++) { q[1 + k] = h.pos[1][k]; q[4 + k] = h.normal[1][k]; } q[7] = T(p); nq++; }
+      }
+      REX_HSTAMP(n1); REX_HACC(K, HT_PAIR, n0, n1); REX_HCNT(K, HC_PAIR_CALLS, 1);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int slot = 0; slot < HITQ_MAX; slot++) {   // rows, slot by slot
+      const bool mine = slot < nq;
+      if (!REX_WAVE_ANY(mine)) break;
+      REX_HSTAMP(r0);
+      if (mine) {
+        const T* q = col + HITQ_BASE + HITQ_WORDS * slot;
+        const T hd = q[0], hp[3] = {q[1], q[2], q[3]}, hn[3] = {q[4], q[5], q[6]};
+        const PairRec<T> pr = m.pair[(int)q[7]];
+        T yaxis[3];
+        for (int k = 0; k < 3; k++) yaxis[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + 3 + k);
+        const bool has_y = pr.t1 == G_PLANE && pr.t2 == G_CAPSULE;   // [3P] mjc_PlaneCapsule: frame y-axis along the capsule
+        add_contact(K, s, m, qvel, pr, hd, hp, hn, has_y ? yaxis : (const T*)nullptr);
+      }
+      REX_HSTAMP(r1); REX_HACC(K, HT_ROWS, r0, r1); REX_HCNT(K, HC_ROW_CALLS, 1);
+    }
+    nq = 0;
+    more = REX_WAVE_ANY((w0 | w1 | w2 | w3) != 0u);
+  }
+  REX_HSTAMP(c2); REX_HACC(K, HT_NARROW_LOOP, c1, c2);
+#endif
 }
 
 // [3P] mj_solPGS on the dual, with qacc carried along: res_i = J_i qacc - aref_i + R_i f_i.  Rows stay in scratch: only
