@@ -805,21 +805,29 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
   T* const col = (T*)__builtin_assume_aligned(&dual(s, 0), 16);
   REX_HSTAMP(p0);
   static_for<0, DUAL_DI + DUAL_NMAX>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
+  T jnext[NV + 2];   // row j + 1 (and its R, aref) is fetched from scratch while row j goes through the solve
+  for (int k = 0; k < NV; k++) jnext[k] = s.J[0][k];
+  jnext[NV] = s.R[0]; jnext[NV + 1] = s.aref[0];
   for (int j = 0; j < n; j++) {
     T x[NV], jr[NV];
-    for (int k = 0; k < NV; k++) { jr[k] = s.J[j][k]; x[k] = jr[k]; }
+    for (int k = 0; k < NV; k++) { jr[k] = jnext[k]; x[k] = jr[k]; }
+    const T Rj = jnext[NV], arefj = jnext[NV + 1];
+    { const int jn = j + 1 < n ? j + 1 : j; for (int k = 0; k < NV; k++) jnext[k] = s.J[jn][k]; jnext[NV] = s.R[jn]; jnext[NV + 1] = s.aref[jn]; }
+    pin_row<0>(jr);
     solve(F, x);
-    T b = -s.aref[j]; for (int k = 0; k < NV; k++) b += jr[k] * K.qacc_smooth[k];
+    T b = -arefj; for (int k = 0; k < NV; k++) b += jr[k] * K.qacc_smooth[k];
     col[DUAL_B + j] = b;
     T* const pa = col + tri(j);
-    int i = 0;
-    for (; i + 1 < j; i += 2) {   // two rows per trip: their scratch reads overlap
-      T a0 = 0, a1 = 0;
-      for (int k = 0; k < NV; k++) { a0 += s.J[i][k] * x[k]; a1 += s.J[i + 1][k] * x[k]; }
-      pa[i] = a0; pa[i + 1] = a1;
+    for (int i = 0; i < j; i += 3) {   // three earlier rows per trip: all their scratch reads are issued before the first is used
+      const int i1 = i + 1 < j ? i + 1 : i, i2 = i + 2 < j ? i + 2 : i;   // (clamped duplicates are computed and dropped)
+      T r0[NV], r1[NV], r2[NV];
+      for (int k = 0; k < NV; k++) { r0[k] = s.J[i][k]; r1[k] = s.J[i1][k]; r2[k] = s.J[i2][k]; }
+      pin_row<0>(r0); pin_row<0>(r1); pin_row<0>(r2);
+      T a0 = 0, a1 = 0, a2 = 0;
+      for (int k = 0; k < NV; k++) { a0 += r0[k] * x[k]; a1 += r1[k] * x[k]; a2 += r2[k] * x[k]; }
+      pa[i] = a0; if (i + 1 < j) pa[i + 1] = a1; if (i + 2 < j) pa[i + 2] = a2;
     }
-    if (i < j) { T a0 = 0; for (int k = 0; k < NV; k++) a0 += s.J[i][k] * x[k]; pa[i] = a0; }
-    T a = s.R[j]; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
+    T a = Rj; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
     pa[j] = a; col[DUAL_DI + j] = rcp_t(a);
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
@@ -843,9 +851,16 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
   REX_HSTAMP(p2); REX_HACC(K, HT_SWEEPS, p1, p2); REX_HCNT(K, HC_SWEEPS, it);
   T x[NV];
   for (int k = 0; k < NV; k++) x[k] = 0;
-  static_for<0, DUAL_NMAX>([&](auto II) {
-    constexpr int i = II;
-    if (i < n) { const T fi = f[i]; s.force[i] = fi; if (fi != T(0)) for (int k = 0; k < NV; k++) x[k] += s.J[i][k] * fi; }
+  static_for<0, DUAL_NMAX / 3>([&](auto CC) {   // J^T f, three rows per trip (reads batched; rows >= n re-read row 0 with f = 0)
+    constexpr int i0 = 3 * CC;
+    if (REX_WAVE_ANY(i0 < n)) {
+      T r[3][NV], fi[3];
+      static_for<0, 3>([&](auto RR) { constexpr int r_ = RR, i = i0 + r_; const int ii = i < n ? i : 0; fi[r_] = i < n ? f[i] : T(0);
+        if (i < n) s.force[i] = fi[r_];
+        for (int k = 0; k < NV; k++) r[r_][k] = s.J[ii][k]; });
+      pin_row<0>(r[0]); pin_row<0>(r[1]); pin_row<0>(r[2]);
+      for (int k = 0; k < NV; k++) x[k] += r[0][k] * fi[0] + r[1][k] * fi[1] + r[2][k] * fi[2];
+    }
   });
   solve(F, x);
   for (int k = 0; k < NV; k++) qacc[k] = K.qacc_smooth[k] + x[k];
