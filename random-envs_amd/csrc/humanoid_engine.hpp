@@ -781,12 +781,30 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
       static_for<0, NP + 2>([&](auto KK) { a[KK] = buf[KK]; });
       pgs_load_row<NC, nxt>(col, buf);   // next row (row 0 of the next sweep after the last one): in flight while this one is used
       pin_row<0>(a);
-      T r0 = a[NP], r1 = 0, r2 = 0, r3 = 0;
-      static_for<0, NP / 4>([&](auto QQ) {
-        constexpr int q = 4 * QQ;
-        r0 += a[q] * f[q]; if constexpr (q + 1 < NC) r1 += a[q + 1] * f[q + 1]; if constexpr (q + 2 < NC) r2 += a[q + 2] * f[q + 2]; if constexpr (q + 3 < NC) r3 += a[q + 3] * f[q + 3];
-      });
-      const T res = (r0 + r1) + (r2 + r3), old = f[i], nf = hmax(T(0), old - res * a[NP + 1]), df = nf - old;
+      T res;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK)
+      if constexpr (sizeof(T) == 4) {   // two packed chains: v_pk_fma_f32 does two of the row's products per instruction
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f acc0 = {a[NP], 0.0f}, acc1 = {0.0f, 0.0f};
+        static_for<0, NP / 4>([&](auto QQ) {
+          constexpr int q = 4 * QQ;
+          const v2f a01 = {a[q], a[q + 1]}, f01 = {f[q], q + 1 < NC ? f[q + 1 < DUAL_NMAX ? q + 1 : 0] : 0.0f};
+          const v2f a23 = {a[q + 2], a[q + 3]}, f23 = {q + 2 < NC ? f[q + 2 < DUAL_NMAX ? q + 2 : 0] : 0.0f, q + 3 < NC ? f[q + 3 < DUAL_NMAX ? q + 3 : 0] : 0.0f};
+          acc0 = __builtin_elementwise_fma(a01, f01, acc0); acc1 = __builtin_elementwise_fma(a23, f23, acc1);
+        });
+        const v2f t = acc0 + acc1;
+        res = t.x + t.y;
+      } else
+#endif
+      {
+        T r0 = a[NP], r1 = 0, r2 = 0, r3 = 0;
+        static_for<0, NP / 4>([&](auto QQ) {
+          constexpr int q = 4 * QQ;
+          r0 += a[q] * f[q]; if constexpr (q + 1 < NC) r1 += a[q + 1] * f[q + 1]; if constexpr (q + 2 < NC) r2 += a[q + 2] * f[q + 2]; if constexpr (q + 3 < NC) r3 += a[q + 3] * f[q + 3];
+        });
+        res = (r0 + r1) + (r2 + r3);
+      }
+      const T old = f[i], nf = hmax(T(0), old - res * a[NP + 1]), df = nf - old;
       f[i] = nf;
       improvement -= T(0.5) * df * df * a[i] + df * res;
     });
