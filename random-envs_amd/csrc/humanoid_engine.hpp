@@ -813,6 +813,25 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
   return it;
 }
 
+// dot product of two nv-vectors; on the device (fp32) eleven v_pk_fma_f32 + one fma instead of 23 fma
+template <class T>
+REX_HD T dot_nv(const T (&a)[NV], const T (&b)[NV]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK)
+  if constexpr (sizeof(T) == 4) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+    static_for<0, NV / 4>([&](auto QQ) { constexpr int q = 4 * QQ;
+      acc0 = __builtin_elementwise_fma(v2f{a[q], a[q + 1]}, v2f{b[q], b[q + 1]}, acc0);
+      acc1 = __builtin_elementwise_fma(v2f{a[q + 2], a[q + 3]}, v2f{b[q + 2], b[q + 3]}, acc1); });
+    acc0 = __builtin_elementwise_fma(v2f{a[20], a[21]}, v2f{b[20], b[21]}, acc0);
+    const v2f t = acc0 + acc1;
+    return (t.x + t.y) + a[22] * b[22];
+  } else
+#endif
+  { T r = 0; for (int k = 0; k < NV; k++) r += a[k] * b[k]; return r; }
+}
+static_assert(NV == 23, "dot_nv is written for nv = 23");
+
 // The same Gauss-Seidel sweeps on the dual: res_i = sum_j A_ij f_j + b_i with A = J M^-1 J^T + diag(R),
 // b = J qacc_smooth - aref ([3P] mj_solPGS works on exactly this matrix).  A, f and b sit in the lane's LDS column, so a
 // sweep costs n^2 LDS reads instead of 2 n nv reads of J / M^-1 J^T rows from scratch (which miss every cache level);
@@ -833,7 +852,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
     { const int jn = j + 1 < n ? j + 1 : j; for (int k = 0; k < NV; k++) jnext[k] = s.J[jn][k]; jnext[NV] = s.R[jn]; jnext[NV + 1] = s.aref[jn]; }
     pin_row<0>(jr);
     solve(F, x);
-    T b = -arefj; for (int k = 0; k < NV; k++) b += jr[k] * K.qacc_smooth[k];
+    const T b = dot_nv(jr, K.qacc_smooth) - arefj;
     col[DUAL_B + j] = b;
     T* const pa = col + tri(j);
     for (int i = 0; i < j; i += 3) {   // three earlier rows per trip: all their scratch reads are issued before the first is used
@@ -841,11 +860,10 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
       T r0[NV], r1[NV], r2[NV];
       for (int k = 0; k < NV; k++) { r0[k] = s.J[i][k]; r1[k] = s.J[i1][k]; r2[k] = s.J[i2][k]; }
       pin_row<0>(r0); pin_row<0>(r1); pin_row<0>(r2);
-      T a0 = 0, a1 = 0, a2 = 0;
-      for (int k = 0; k < NV; k++) { a0 += r0[k] * x[k]; a1 += r1[k] * x[k]; a2 += r2[k] * x[k]; }
+      const T a0 = dot_nv(r0, x), a1 = dot_nv(r1, x), a2 = dot_nv(r2, x);
       pa[i] = a0; if (i + 1 < j) pa[i + 1] = a1; if (i + 2 < j) pa[i + 2] = a2;
     }
-    T a = Rj; for (int k = 0; k < NV; k++) a += jr[k] * x[k];
+    const T a = Rj + dot_nv(jr, x);
     pa[j] = a; col[DUAL_DI + j] = rcp_t(a);
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
