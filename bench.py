@@ -67,7 +67,14 @@ def cpu_baseline(env_id, batch, steps, seed=0, min_seconds=12.0):
         oracle_rollout(kind, q, v, acts, xi, nthreads=cores)
         reps += 1; dt = time.perf_counter() - t0
     steps = steps * reps
-    return dict(value=batch * steps / dt, unit="env-steps/s", cores=cores, kind="port",
+    # the reference's own usage shape: ONE env stepped by ONE core; ~2 s
+    n1, t1, r1 = min(steps // reps, acts.shape[0]), 0.0, 0
+    t0 = time.perf_counter()
+    while t1 < 2.0 and r1 < 100000:
+        oracle_rollout(kind, q[:1], v[:1], acts[:n1, :1], xi[:1], nthreads=1)
+        r1 += 1; t1 = time.perf_counter() - t0
+    one_core = n1 * r1 / t1
+    return dict(value=batch * steps / dt, unit="env-steps/s", cores=cores, kind="port", one_env_one_core=one_core,
                 sample="%s: %d envs x %d env-steps (%d-step rollouts from reset states, %d repeats), U(-a,a) actions, "
                        "xi nominal+-10%%, fp64, %d threads, %.1f s" % (env_id, batch, steps, steps // reps, reps, cores, dt))
 
