@@ -609,41 +609,6 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
     cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;
   });
   REX_HSTAMP(c1); REX_HACC(K, HT_BROAD, c0, c1);
-#if defined(REX_UNION_NARROW)
-  // one runtime loop over the pairs and ONE inlined copy of the narrow phase and of the row construction (they are large:
-  // instruction fetch, not arithmetic, is what a second copy costs); the mask words stay in registers
-  constexpr int NW = (kPairs.n + 31) / 32;
-  static_assert(NW == 4, "pair mask words");
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
-  for (int p = 0; p < kPairs.n; p++) {
-    const int w = p >> 5;
-    const unsigned cw = w == 0 ? cand[0] : (w == 1 ? cand[1] : (w == 2 ? cand[2] : cand[3]));
-    const bool mine = (cw >> (p & 31)) & 1u;
-    if (!REX_WAVE_ANY(mine)) continue;
-    REX_HSTAMP(n0);
-    const PairRec<T> pr = m.pair[p];   // by value: one 64-byte uniform load
-    Hits<T> h; T yaxis[3]; bool has_y;
-    h.n = 0;
-    if (mine) collide_pair(m, s, pr, h, yaxis, has_y);
-    REX_HSTAMP(n1); REX_HACC(K, HT_PAIR, n0, n1); REX_HCNT(K, HC_PAIR_CALLS, 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
-    for (int k = 0; k < 2; k++) {
-      if (!REX_WAVE_ANY(k < h.n)) break;
-      // select instead of indexing: the hits stay in registers
-      const T hd = k ? h.dist[1] : h.dist[0];
-      const T hp[3] = {k ? h.pos[1][0] : h.pos[0][0], k ? h.pos[1][1] : h.pos[0][1], k ? h.pos[1][2] : h.pos[0][2]};
-      const T hn[3] = {k ? h.normal[1][0] : h.normal[0][0], k ? h.normal[1][1] : h.normal[0][1], k ? h.normal[1][2] : h.normal[0][2]};
-      REX_HSTAMP(r0);
-      if (k < h.n) add_contact(K, s, m, qvel, pr, hd, hp, hn, has_y ? yaxis : (const T*)nullptr);
-      REX_HSTAMP(r1); REX_HACC(K, HT_ROWS, r0, r1); REX_HCNT(K, HC_ROW_CALLS, 1);
-    }
-  }
-  REX_HSTAMP(c2); REX_HACC(K, HT_NARROW_LOOP, c1, c2);
-#else
   // Narrow phase per LANE, not per pair: every lane walks its own candidate bits in table order (the PGS row order depends on
   // it) with its own pair record, so a wave needs as many trips as its busiest lane has candidates (~10) instead of one per
   // pair of the union over its lanes (~42).  Hits are queued in the free tail of the LDS column and turned into rows slot by
@@ -694,7 +659,6 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
     more = REX_WAVE_ANY((w0 | w1 | w2 | w3) != 0u);
   }
   REX_HSTAMP(c2); REX_HACC(K, HT_NARROW_LOOP, c1, c2);
-#endif
 }
 
 // [3P] mj_solPGS on the dual, with qacc carried along: res_i = J_i qacc - aref_i + R_i f_i.  Rows stay in scratch: only
