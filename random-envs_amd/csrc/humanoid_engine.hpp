@@ -133,10 +133,12 @@ template <class T> REX_HD T habs(T a) { return a < T(0) ? -a : a; }
 template <class T> REX_HD T hmax(T a, T b) { return a > b ? a : b; }
 template <class T> REX_HD T hmin(T a, T b) { return a < b ? a : b; }
 REX_HD void hsincos(float a, float& s, float& c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(REX_LIBM_SINCOS) && defined(__HIP_DEVICE_COMPILE__)
   sincosf(a, &s, &c);
-#else
+#elif defined(REX_LIBM_SINCOS)
   s = sinf(a); c = cosf(a);
+#else
+  sincos_poly(a, s, c);
 #endif
 }
 REX_HD void hsincos(double a, double& s, double& c) { s = sin(a); c = cos(a); }

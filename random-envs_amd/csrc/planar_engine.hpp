@@ -24,10 +24,12 @@ namespace rex {
 REX_HD void sincos_t(float a, float& s, float& c) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(REX_FAST_SINCOS)
   s = __sinf(a); c = __cosf(a);
-#elif defined(__HIP_DEVICE_COMPILE__)
+#elif defined(REX_LIBM_SINCOS) && defined(__HIP_DEVICE_COMPILE__)
   sincosf(a, &s, &c);
-#else
+#elif defined(REX_LIBM_SINCOS)
   s = sinf(a); c = cosf(a);
+#else
+  sincos_poly(a, s, c);
 #endif
 }
 REX_HD void sincos_t(double a, double& s, double& c) { s = sin(a); c = cos(a); }
