@@ -578,6 +578,17 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     T q1 = T(0), q2 = T(0), d0 = T(0);
     static_for<0, S::NV>([&](auto II) { q1 += sr[II] * (Ma[II] - qfrc_smooth[II]); q2 += sr[II] * Ms[II]; d0 += sr[II] * g[II]; });
     unsigned m_lim, m_e1, m_e2, m_e3, m_self;   // rows active at the last evaluated alpha
+    // every row is linear in alpha: x(alpha) = r + alpha v with r = J qacc - aref, v = J sr.  The slot products J qacc, J sr
+    // are formed once per Newton iteration; an evaluation of phi' is then a few multiply-adds per slot.
+    T lt[NC], ln[NC], lvt[NC], lvn[NC];
+    static_for<0, S::NG>([&](auto GG) {
+      constexpr int gg = GG; constexpr int b = S::geom_body[gg];
+      static_for<0, 2>([&](auto EE) {
+        constexpr int k = 2 * gg + EE;
+        lt[k] = ln[k] = lvt[k] = lvn[k] = T(0);
+        if (REX_WAVE_ANY((C.con_mask >> k) & 1u)) jdot2<T, S, b>(K, cpx[k], cpz[k], qacc, sr, lt[k], ln[k], lvt[k], lvn[k]);
+      });
+    });
     auto deriv = [&](T a, T& d1, T& d2) {
       REX_COUNT(ls_evals, 1);
       m_lim = m_e1 = m_e2 = m_e3 = m_self = 0u;
@@ -589,13 +600,13 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           if (on) m_lim |= 1u << j;
           T dd = on ? C.lD[j] : T(0); d1 += dd * x * lv; d2 += dd * lv * lv; } });
       static_for<0, S::NG>([&](auto GG) {
-        constexpr int gg = GG; constexpr int b = S::geom_body[gg];
+        constexpr int gg = GG;
         static_for<0, 2>([&](auto EE) {
           constexpr int k = 2 * gg + EE;
           const bool act = (C.con_mask >> k) & 1u;
           if (REX_WAVE_ANY(act)) {
             const T mu = P.mu[gg];
-            T jt, jn, vt, vn; jdot2<T, S, b>(K, cpx[k], cpz[k], qacc, sr, jt, jn, vt, vn);
+            const T jt = lt[k], jn = ln[k], vt = lvt[k], vn = lvn[k];
             T r0 = jn + mu * jt - (C.an[k] + C.at[k]), r1 = jn - mu * jt - (C.an[k] - C.at[k]), r2 = jn - C.an[k];
             T v0 = vn + mu * vt, v1 = vn - mu * vt, v2 = vn;
             T x0 = r0 + a * v0, x1 = r1 + a * v1, x2 = r2 + a * v2;
