@@ -1,0 +1,31 @@
+"""Diagnostic: distribution over the waves of one launch of the cycles spent in the substeps (build with -DREX_WAVETIME).
+At B = 32 768 every wave has its own SIMD, so the kernel time is the slowest wave's."""
+import os, sys, ctypes
+os.environ["REX_LIB"] = "librex_hip_wavetime.so"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, random_envs_amd as rex
+from random_envs_amd import _native
+for eid in sys.argv[1:] or ["RandomHopper-v0"]:
+    B = 32768
+    env = rex.make(eid, batch=B, seed=0)
+    nom = torch.tensor(env.original_task)
+    env.set_dr_distribution("uniform", torch.stack([0.9 * nom, 1.1 * nom], 1).flatten().tolist()); env.set_dr_training(True); env.reset()
+    g = torch.Generator().manual_seed(0)
+    acts = [(torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1).cuda() for _ in range(8)]
+    for k in range(300): env.step_soa(acts[k % 8])
+    rows, infos = [], []
+    info = (ctypes.c_ulonglong * (1024 * 8))(); torch.cuda.synchronize(); _native.lib().rex_debug_waveinfo(info, 1024)
+    for k in range(20):
+        env.step_soa(acts[k % 8]); torch.cuda.synchronize()
+        out = (ctypes.c_ulonglong * 1024)(); _native.lib().rex_debug_wavetime(out, 1024)
+        _native.lib().rex_debug_waveinfo(info, 1024)
+        rows.append(np.array(list(out), dtype=np.float64)); infos.append(np.array(list(info), dtype=np.float64).reshape(1024, 8))
+    w = np.stack(rows); I = np.stack(infos)
+    print(eid, "cycles per wave-step: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f  -> max/mean %.2f" %
+          (w.mean(), np.percentile(w, 50), np.percentile(w, 90), np.percentile(w, 99), w.max(1).mean(), w.max(1).mean() / w.mean()))
+    print("   the same wave slow twice in a row (rank correlation of consecutive launches): %.2f" % np.corrcoef(w[:-1].ravel(), w[1:].ravel())[0, 1])
+    names = ["solves", "iters", "pass1", "pass2", "ls_evals", "nocon", "slots_active", "selfpath"]
+    slow = w > np.percentile(w, 98); fast = w < np.percentile(w, 60)
+    print("   per wave-step counts, typical waves (< p60) vs slow waves (> p98):")
+    for k, nm in enumerate(names): print("     %-13s %8.1f %8.1f" % (nm, I[..., k][fast].mean(), I[..., k][slow].mean()))
+    env.close()

@@ -445,6 +445,11 @@ inline GlobalStats& gstats() { static GlobalStats g{}; return g; }
 extern __device__ unsigned long long g_kstats[8];
 enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4, KS_nocon = 5, KS_slots_active = 6 };
 #define REX_COUNT(field, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_kstats[KS_##field], (unsigned long long)(n)); } while (0)
+#elif defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
+// diagnostic build only: the same counts per WAVE (slot = workgroup index), next to the wave's cycle count
+extern __device__ unsigned long long g_waveinfo[8192][8];
+enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4, KS_nocon = 5, KS_slots_active = 6, KS_selfpath = 7 };
+#define REX_COUNT(field, n) do { if ((threadIdx.x & 63) == 0) g_waveinfo[blockIdx.x & 8191][KS_##field] += (unsigned long long)(n); } while (0)
 #else
 #define REX_COUNT(field, n) ((void)0)
 #endif
@@ -713,18 +718,27 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
 #else
   REX_COUNT(solves, 1); if (!C.any) REX_COUNT(nocon, 1); REX_COUNT(slots_active, __builtin_popcount(C.con_mask));
 #endif
-  bool self_path = false;
-  if constexpr (S::NSELF > 0) self_path = REX_WAVE_ANY(C.self_possible);
-  if (self_path) {   // rare: a capsule-capsule self contact may exist somewhere in this wave
-    SelfRows<T, S> R;
-    make_self_rows<T, S>(v, G, sp, K, R);
-    st = solve_newton<T, S, true>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max);
-  } else if (REX_WAVE_ANY(C.any)) {
-    SelfRows<T, S> R; R.mask = 0u;
-    st = solve_newton<T, S, false>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max);
-  } else {
-    static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+  // Capsule-capsule self contacts (hopper): the bounding-circle cull is loose -- a sharply folded leg passes it for hundreds of
+  // steps without touching -- and the kernel time at B = 32 768 is the SLOWEST wave's, so the dearer solver instantiation is
+  // entered only when the narrow phase has actually produced a row somewhere in the wave.
+  SelfRows<T, S> R; R.mask = 0u;
+  bool self_rows = false;
+  if constexpr (S::NSELF > 0) {
+    if (REX_WAVE_ANY(C.self_possible)) {
+#if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
+      REX_COUNT(selfpath, 1);
+#endif
+      make_self_rows<T, S>(v, G, sp, K, R);
+      self_rows = REX_WAVE_ANY(R.mask != 0u);
+    }
   }
+  int mode = self_rows ? 2 : (REX_WAVE_ANY(C.any) ? 1 : 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  mode = __builtin_amdgcn_readfirstlane(mode);   // wave-uniform by construction: make it a scalar branch
+#endif
+  if (mode == 2) { if constexpr (S::NSELF > 0) st = solve_newton<T, S, true>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max); }
+  else if (mode == 1) st = solve_newton<T, S, false>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max);
+  else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
   REX_STAMP(t_5);
   REX_TACC(0, t_0, t_1); REX_TACC(1, t_1, t_2); REX_TACC(2, t_2, t_3); REX_TACC(3, t_3, t_4); REX_TACC(4, t_4, t_5);
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)

@@ -35,6 +35,16 @@ extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build 
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_ktime), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
   unsigned long long z[96] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rex::g_ktime), z, sizeof z); return 0; }
 #endif
+#if defined(REX_WAVETIME)
+// diagnostic build only: cycles every wave of the last planar / humanoid step launch spent in its substeps (the kernel time at
+// B = 32 768 is the SLOWEST wave's, not the average)
+namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; }
+extern "C" int rex_debug_waveinfo(unsigned long long* out, int n) {   // n waves x 8 counters, then zeroed
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_waveinfo), sizeof(unsigned long long) * 8 * (n < 8192 ? n : 8192)) != hipSuccess) return -1;
+  static unsigned long long z[8192][8]; return hipMemcpyToSymbol(HIP_SYMBOL(rex::g_waveinfo), z, sizeof z) == hipSuccess ? 0 : -1; }
+extern "C" int rex_debug_wavetime(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavetime), sizeof(unsigned long long) * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1; }
+#endif
 #if defined(REX_KSTATS)
 namespace rex { __device__ unsigned long long g_kstats[8]; }
 extern "C" int rex_debug_kstats(unsigned long long* out) {   // diagnostic build only (not in rex.h)
@@ -250,7 +260,7 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   LaneParams<float, S> P; lane_params(S{}, xi, P);
   // the dynamics are invariant to the root x translation: integrate the step from x = 0 so the
   // forward-progress reward (posafter - posbefore)/dt keeps full fp32 resolution far from the origin
-#if defined(REX_KTIME)
+#if defined(REX_KTIME) || defined(REX_WAVETIME)
   unsigned long long tk0 = __builtin_amdgcn_s_memtime();
 #endif
   const float x_before = q[0];
@@ -262,6 +272,9 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
 #if defined(REX_KTIME)
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[5], __builtin_amdgcn_s_memtime() - tk0);
+#endif
+#if defined(REX_WAVETIME)
+  if ((threadIdx.x & 63) == 0) g_wavetime[blockIdx.x & 8191] = __builtin_amdgcn_s_memtime() - tk0;
 #endif
   const float dx = q[0];
   q[0] = x_before + dx;
