@@ -204,7 +204,7 @@ struct Constraints {
   T lsig[S::NB], lD[S::NB], laref[S::NB];   // joint limits: row = lsig * e_dof
   unsigned lim_mask;
   bool any;              // any row at all in this lane
-  bool self_possible;    // a capsule-capsule self contact may exist (bounding-circle cull)
+  unsigned self_possible;   // bit p: capsule-capsule self pair p may be in contact (bounding-circle cull)
 };
 // capsule-capsule self contacts (condim 1); only materialised on the rare path
 template <class T, class S>
@@ -288,7 +288,7 @@ REX_HD void capsule_pose(const Kin<T, S>& K, const PlanarGeom<T, S>& G, T (&p)[2
   p[0] = K.A[b][0] + T(0.5) * (e1x + e2x); p[1] = K.A[b][1] + T(0.5) * (e1z + e2z);
   T hx = T(0.5) * (e1x - e2x), hz = T(0.5) * (e1z - e2z);
   l = sqrt_t(hx * hx + hz * hz);
-  a[0] = hx / l; a[1] = hz / l;
+  const T il = rcp_t(l); a[0] = hx * il; a[1] = hz * il;
 }
 
 // closest points of two 2-D segments ([3P] mjc_CapsuleCapsule restated in the plane), then
@@ -305,7 +305,7 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
     T len = sqrt_t(dx * dx + dz * dz), d = len - r1 - r2;
     if (d > margin) return;
     T ux = T(1), uz = T(0);
-    if (len >= T(1e-15)) { ux = dx / len; uz = dz / len; }
+    if (len >= T(1e-15)) { const T il = rcp_t(len); ux = dx * il; uz = dz * il; }
     T px_ = c1x + ux * (r1 + d * T(0.5)), pz_ = c1z + uz * (r1 + d * T(0.5));
     if (!H.h0) { H.h0 = true; H.d0 = d; H.nx0 = ux; H.nz0 = uz; H.cx0 = px_; H.cz0 = pz_; }
     else if (!H.h1) { H.h1 = true; H.d1 = d; H.nx1 = ux; H.nz1 = uz; H.cx1 = px_; H.cz1 = pz_; }
@@ -314,9 +314,10 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
   T ma = a1[0] * a1[0] + a1[1] * a1[1], mb = -(a1[0] * a2[0] + a1[1] * a2[1]), mc = a2[0] * a2[0] + a2[1] * a2[1];
   T u = -(a1[0] * difx + a1[1] * difz), v = a2[0] * difx + a2[1] * difz, det = ma * mc - mb * mb;
   if (abs_t(det) >= T(1e-15)) {
-    T x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-    if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) / mc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) / mc; }
-    if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) / ma; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) / ma; }
+    const T idet = rcp_t(det), imc = rcp_t(mc), ima = rcp_t(ma);
+    T x1 = (mc * u - mb * v) * idet, x2 = (ma * v - mb * u) * idet;
+    if (x1 > l1) { x1 = l1; x2 = (v - mb * l1) * imc; } else if (x1 < -l1) { x1 = -l1; x2 = (v + mb * l1) * imc; }
+    if (x2 > l2) { x2 = l2; x1 = (u - mb * l2) * ima; } else if (x2 < -l2) { x2 = -l2; x1 = (u + mb * l2) * ima; }
     if (x1 > l1) x1 = l1; else if (x1 < -l1) x1 = -l1;
     sphere(p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p2[0] + a2[0] * x2, p2[1] + a2[1] * x2);
     return;
@@ -385,7 +386,7 @@ REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const Pla
   });
   C.lim_mask = lim_mask; C.con_mask = con_mask;
   // bounding-circle cull of the capsule-capsule self pairs
-  bool sp_any = false;
+  unsigned sp_any = 0u;
   if constexpr (S::NSELF > 0) {
     static_for<0, S::NSELF>([&](auto PP) {
       constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
@@ -397,7 +398,7 @@ REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const Pla
       T la2 = (G.e1[ga][0] - G.e2[ga][0]) * (G.e1[ga][0] - G.e2[ga][0]) + (G.e1[ga][1] - G.e2[ga][1]) * (G.e1[ga][1] - G.e2[ga][1]);
       T lb2 = (G.e1[gb][0] - G.e2[gb][0]) * (G.e1[gb][0] - G.e2[gb][0]) + (G.e1[gb][1] - G.e2[gb][1]) * (G.e1[gb][1] - G.e2[gb][1]);
       T reach = T(0.5) * (sqrt_t(la2) + sqrt_t(lb2)) + G.radius[ga] + G.radius[gb] + sp.con_margin;
-      sp_any = sp_any || (dx * dx + dz * dz <= reach * reach);
+      sp_any |= (dx * dx + dz * dz <= reach * reach) ? (1u << p) : 0u;
     });
   }
   C.self_possible = sp_any;
@@ -406,30 +407,33 @@ REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const Pla
 
 template <class T, class S>
 REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const SolParams<T>& sp, const Kin<T, S>& K,
-                           SelfRows<T, S>& R) {
+                           unsigned possible, SelfRows<T, S>& R) {
   unsigned mask = 0;
   if constexpr (S::NSELF > 0) {
     static_for<0, S::NSELF>([&](auto PP) {
       constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
       constexpr int ba = S::geom_body[ga], bb = S::geom_body[gb];
-      T p1[2], a1[2], p2[2], a2[2], l1, l2;
-      capsule_pose<T, S, ga>(K, G, p1, a1, l1); capsule_pose<T, S, gb>(K, G, p2, a2, l2);
-      Hit2<T> H;
-      capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, H);
-      static_for<0, 2>([&](auto KK) {
-        constexpr int k = KK; constexpr int r = 2 * p + k;
-        const bool hit_k = k == 0 ? H.h0 : H.h1; const T dist_k = k == 0 ? H.d0 : H.d1;
-        bool act = hit_k && dist_k < sp.con_margin;
-        if (act) {
-          mask |= 1u << r;
-          R.px[r] = k == 0 ? H.cx0 : H.cx1; R.pz[r] = k == 0 ? H.cz0 : H.cz1; R.nx[r] = k == 0 ? H.nx0 : H.nx1; R.nz[r] = k == 0 ? H.nz0 : H.nz1;
-          T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist_k - sp.con_margin));
-          R.D[r] = imp / max_t(T(1e-15), (T(1) - imp) * (G.tran_invw[ba] + G.tran_invw[bb]));
-          T ta, na, tb, nb; jdot<T, S, ba>(K, R.px[r], R.pz[r], v, ta, na); jdot<T, S, bb>(K, R.px[r], R.pz[r], v, tb, nb);
-          T vel = R.nx[r] * (tb - ta) + R.nz[r] * (nb - na);
-          R.aref[r] = -sp.con_B * vel - sp.con_K * imp * (dist_k - sp.con_margin);
-        } else { R.px[r] = R.pz[r] = R.nx[r] = R.nz[r] = R.D[r] = R.aref[r] = T(0); }
-      });
+      static_for<0, 2>([&](auto KK) { constexpr int r = 2 * p + KK; R.px[r] = R.pz[r] = R.nx[r] = R.nz[r] = R.D[r] = R.aref[r] = T(0); });
+      if (REX_WAVE_ANY((possible >> p) & 1u)) {   // pairs whose bounding circles are apart in every lane cost nothing
+        T p1[2], a1[2], p2[2], a2[2], l1, l2;
+        capsule_pose<T, S, ga>(K, G, p1, a1, l1); capsule_pose<T, S, gb>(K, G, p2, a2, l2);
+        Hit2<T> H;
+        capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, H);
+        static_for<0, 2>([&](auto KK) {
+          constexpr int k = KK; constexpr int r = 2 * p + k;
+          const bool hit_k = k == 0 ? H.h0 : H.h1; const T dist_k = k == 0 ? H.d0 : H.d1;
+          bool act = hit_k && dist_k < sp.con_margin;
+          if (act) {
+            mask |= 1u << r;
+            R.px[r] = k == 0 ? H.cx0 : H.cx1; R.pz[r] = k == 0 ? H.cz0 : H.cz1; R.nx[r] = k == 0 ? H.nx0 : H.nx1; R.nz[r] = k == 0 ? H.nz0 : H.nz1;
+            T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist_k - sp.con_margin));
+            R.D[r] = imp * rcp_t(max_t(T(1e-15), (T(1) - imp) * (G.tran_invw[ba] + G.tran_invw[bb])));
+            T ta, na, tb, nb; jdot<T, S, ba>(K, R.px[r], R.pz[r], v, ta, na); jdot<T, S, bb>(K, R.px[r], R.pz[r], v, tb, nb);
+            T vel = R.nx[r] * (tb - ta) + R.nz[r] * (nb - na);
+            R.aref[r] = -sp.con_B * vel - sp.con_K * imp * (dist_k - sp.con_margin);
+          }
+        });
+      }
     });
   }
   R.mask = mask;
@@ -724,11 +728,11 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   SelfRows<T, S> R; R.mask = 0u;
   bool self_rows = false;
   if constexpr (S::NSELF > 0) {
-    if (REX_WAVE_ANY(C.self_possible)) {
+    if (REX_WAVE_ANY(C.self_possible != 0u)) {
 #if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
       REX_COUNT(selfpath, 1);
 #endif
-      make_self_rows<T, S>(v, G, sp, K, R);
+      make_self_rows<T, S>(v, G, sp, K, C.self_possible, R);
       self_rows = REX_WAVE_ANY(R.mask != 0u);
     }
   }
