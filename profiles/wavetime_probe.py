@@ -11,8 +11,9 @@ for eid in sys.argv[1:] or ["RandomHopper-v0"]:
     nom = torch.tensor(env.original_task)
     env.set_dr_distribution("uniform", torch.stack([0.9 * nom, 1.1 * nom], 1).flatten().tolist()); env.set_dr_training(True); env.reset()
     g = torch.Generator().manual_seed(0)
-    acts = [(torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1).cuda() for _ in range(8)]
-    for k in range(300): env.step_soa(acts[k % 8])
+    amp = 0.4 if "Humanoid" in eid else 1.0
+    acts = [((torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1) * amp).cuda() for _ in range(8)]
+    for k in range(80 if "Humanoid" in eid else 300): env.step_soa(acts[k % 8])
     rows, infos = [], []
     info = (ctypes.c_ulonglong * (1024 * 8))(); torch.cuda.synchronize(); _native.lib().rex_debug_waveinfo(info, 1024)
     for k in range(20):

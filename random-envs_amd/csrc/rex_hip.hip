@@ -436,12 +436,18 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
   int t = s.t[i] + 1;
   if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
                              (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
+#if defined(REX_WAVETIME)
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
   hum::env_step(c_hum, L, q, v, a, xp, kn, sc, r, dn, [&](int k, float val) {
     // noise only on the qpos / qvel slices (random_humanoid.py:193-204)
     if (fl.noisy && k < 45) val += fl.noise_std * rocrand_normal(&st);
     (obs + k * B)[i] = val;
     if (term_obs) (term_obs + k * B)[i] = val;
   });
+#if defined(REX_WAVETIME)
+  if ((threadIdx.x & 63) == 0) g_wavetime[blockIdx.x & 8191] = __builtin_amdgcn_s_memtime() - tk0;
+#endif
 #if defined(REX_KTIME)
   for (int k = 0; k < HT_SLOTS; k++) {   // one flush per wave and kernel: the wave maximum of every accumulator
     unsigned long long v = kn.tacc[k];
