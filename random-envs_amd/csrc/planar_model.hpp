@@ -208,7 +208,10 @@ REX_HD void derive_model(const T* size, PlanarGeom<T, S>& G, T (&nominal_mass)[S
   sp.lim_K = T(1) / (sp.lim_dmax * sp.lim_dmax * tc * tc); sp.lim_B = T(2) / (sp.lim_dmax * tc);
   // measured on MI355X at B = 32768 (kernel ms, ls_max/warm): hopper 16/0 .247, 3/1 .205; walker2d .476 -> .386;
   // half-cheetah (one evaluation per mj_step: the previous qacc is a poor guess) 16/0 .152, 3/0 .143, 3/1 .165
-  sp.ls_max = 3; sp.warm = S::RK4 ? 1 : 0;
+  // Re-measured once the kernel time was understood to be the SLOWEST wave's (kernel ms at ls_max 0/1/2/3): hopper
+  // .138/.139/.147/.151, half-cheetah .117/.129/.134/.135, walker2d .307/.323/.345/.353 -- but without any line search (0) a few
+  // walker2d waves hit the iteration cap, and 1 still did (4 waves in 1 500 steps); every env keeps at least one safeguarded step.
+  sp.ls_max = S::KIND == 3 ? 2 : 1; sp.warm = S::RK4 ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
