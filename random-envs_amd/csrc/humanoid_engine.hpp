@@ -833,20 +833,25 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
     pa[j] = a; col[DUAL_DI + j] = rcp_t(a);
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
-  // Sweeps over the smallest of five fixed sizes that holds every lane of the wave.
+  // Sweeps over the smallest of eight fixed sizes that holds every lane of the wave.
   int it;
   T f[DUAL_NMAX];
   static_for<0, DUAL_NMAX>([&](auto II) { f[II] = T(0); });
   {
-    int lvl = REX_WAVE_ANY(n > 16) ? 4 : (REX_WAVE_ANY(n > 12) ? 3 : (REX_WAVE_ANY(n > 8) ? 2 : (REX_WAVE_ANY(n > 4) ? 1 : 0)));
+    // the launch ends with its slowest wave and sweeps cost 50 x NC rows: sizes in steps of two above 8
+    int lvl = 0;
+    static_for<0, 8>([&](auto LL) { constexpr int thr[8] = {4, 8, 10, 12, 14, 16, 18, 21}; if (REX_WAVE_ANY(n > thr[LL])) lvl = LL + 1; });
 #if defined(__HIP_DEVICE_COMPILE__)
     lvl = __builtin_amdgcn_readfirstlane(lvl);
 #endif
     switch (lvl) {
       case 0: it = pgs_sweeps<4>(m, col, n, f); break;
       case 1: it = pgs_sweeps<8>(m, col, n, f); break;
-      case 2: it = pgs_sweeps<12>(m, col, n, f); break;
-      case 3: it = pgs_sweeps<16>(m, col, n, f); break;
+      case 2: it = pgs_sweeps<10>(m, col, n, f); break;
+      case 3: it = pgs_sweeps<12>(m, col, n, f); break;
+      case 4: it = pgs_sweeps<14>(m, col, n, f); break;
+      case 5: it = pgs_sweeps<16>(m, col, n, f); break;
+      case 6: it = pgs_sweeps<18>(m, col, n, f); break;
       default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
     }
   }
