@@ -24,8 +24,9 @@ for eid in sys.argv[1:] or ["RandomHopper-v0"]:
     w = np.stack(rows); I = np.stack(infos)
     print(eid, "cycles per wave-step: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f  -> max/mean %.2f" %
           (w.mean(), np.percentile(w, 50), np.percentile(w, 90), np.percentile(w, 99), w.max(1).mean(), w.max(1).mean() / w.mean()))
+    print("   cycles in the fused reset path per wave-step: mean %.0f  p90 %.0f  max %.0f" % (I[..., 1].mean(), np.percentile(I[..., 1], 90), I[..., 1].max(1).mean()))
     print("   the same wave slow twice in a row (rank correlation of consecutive launches): %.2f" % np.corrcoef(w[:-1].ravel(), w[1:].ravel())[0, 1])
-    names = ["solves", "iters", "pass1", "pass2", "ls_evals", "nocon", "slots_active", "selfpath"]
+    names = ["solves", "reset cycles", "pass1", "pass2", "ls_evals", "nocon", "slots_active", "selfpath"]
     slow = w > np.percentile(w, 98); fast = w < np.percentile(w, 60)
     print("   per wave-step counts, typical waves (< p60) vs slow waves (> p98):")
     for k, nm in enumerate(names): print("     %-13s %8.1f %8.1f" % (nm, I[..., k][fast].mean(), I[..., k][slow].mean()))

@@ -313,7 +313,13 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
   // auto-reset fused into the step launch: finished lanes restart here (saves the masked reset launch and
   // the kernel boundary, ~10 % of a hopper step at B = 32768)
+#if defined(REX_WAVETIME)
+  const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
   if (fused_reset && d) planar_reset_lane<S>(s, fl, dr, resample, 1, i, obs);
+#if defined(REX_WAVETIME)
+  if ((threadIdx.x & 63) == 0) { g_waveinfo[blockIdx.x & 8191][1] += __builtin_amdgcn_s_memtime() - tr0; }   // slot 1 ("iters", unused): cycles in the fused reset
+#endif
 }
 
 // reset_model (random_hopper.py:112-120, random_half_cheetah.py:123-131, random_walker2d.py:144-153)
