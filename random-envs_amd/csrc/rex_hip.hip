@@ -38,7 +38,9 @@ extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build 
 #if defined(REX_WAVETIME)
 // diagnostic build only: cycles every wave of the last planar / humanoid step launch spent in its substeps (the kernel time at
 // B = 32 768 is the SLOWEST wave's, not the average)
-namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; }
+namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; __device__ unsigned long long g_wavehum[1024][16]; }
+extern "C" int rex_debug_wavehum(unsigned long long* out) {   // humanoid: per-wave phase accumulators of the last launch (-DREX_KTIME -DREX_WAVETIME)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavehum), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -1; }
 extern "C" int rex_debug_waveinfo(unsigned long long* out, int n) {   // n waves x 8 counters, then zeroed
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_waveinfo), sizeof(unsigned long long) * 8 * (n < 8192 ? n : 8192)) != hipSuccess) return -1;
   static unsigned long long z[8192][8]; return hipMemcpyToSymbol(HIP_SYMBOL(rex::g_waveinfo), z, sizeof z) == hipSuccess ? 0 : -1; }
@@ -459,6 +461,9 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
     unsigned long long v = kn.tacc[k];
     for (int off = 32; off > 0; off >>= 1) { unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[8 + k], v);
+#if defined(REX_WAVETIME)
+    if ((threadIdx.x & 63) == 0 && k < 16) g_wavehum[blockIdx.x & 1023][k] = v;
+#endif
   }
 #endif
   bool finite = true;
