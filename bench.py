@@ -79,13 +79,48 @@ def cpu_baseline(env_id, batch, steps, seed=0, min_seconds=12.0):
                        "xi nominal+-10%%, fp64, %d threads, %.1f s" % (env_id, batch, steps, steps // reps, reps, cores, dt))
 
 
+def source_digest():
+    """sha256 over the kernel sources: ties a committed PMC traffic figure to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "random-envs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(env_id):
+    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/collect.sh writes
+    profiles/hbm_traffic.json together with the digest of the sources it profiled).  Returns (bytes or None, stale)."""
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tp):
+        return None, False
+    try:
+        rec = json.load(open(tp))
+    except Exception:
+        return None, False
+    rec = rec.get(env_id, rec if env_id == ENV_ID else {})
+    if not rec or "bytes_per_launch" not in rec:
+        return None, False
+    if rec.get("source_digest") != source_digest():
+        return None, True          # kernels changed since the PMC run: do not report a stale figure
+    return rec["bytes_per_launch"], False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="envs per GPU")
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="envs per GPU (weak) / global batch (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch envs on every GPU; strong: --batch envs in total, split by index (SURVEY 8d north-star point)")
     ap.add_argument("--env", default=ENV_ID)
+    ap.add_argument("--replay", action="store_true",
+                    help="second workload (SURVEY 8 f2): ONE logged transition replayed under a fresh candidate xi per env and step "
+                         "(set_task + set_sim_state + step, no auto-reset)")
+    ap.add_argument("--counter-every", type=int, default=256, help="steps between asynchronous all-reduces of the step counter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the per-launch HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the launch path on one GPU)")
@@ -102,13 +137,18 @@ def main():
     torch.cuda.set_device(local_rank)
     if rank == 0:
         graft.build()
-    sharding.init(args.backend, torch.device("cuda", local_rank))   # "nccl" = RCCL over xGMI; no-op at N=1
+    dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
+    sharding.init(args.backend, dev)   # "nccl" = RCCL over xGMI; no-op at N=1
     sharding.barrier()
     import random_envs_amd as rex
 
-    B = args.batch
-    env_offset, _ = sharding.shard(B, rank)                    # index-sharded batch, weak scaling
-    env = rex.make(args.env, batch=B, device=local_rank, seed=0, env_offset=env_offset)
+    if args.scaling == "strong":
+        env_offset, B = sharding.shard_strong(args.batch, rank, world)   # fixed global batch split by index
+    else:
+        env_offset, B = sharding.shard(args.batch, rank)                 # fixed per-GPU batch
+    env = rex.make(args.env, batch=B, device=local_rank, seed=0, env_offset=env_offset,
+                   autoreset=not args.replay)
     nom = torch.tensor(env.original_task)
     env.set_dr_distribution("uniform", torch.stack([0.9 * nom, 1.1 * nom], 1).flatten().tolist())
     env.set_dr_training(True)
@@ -117,54 +157,89 @@ def main():
     nact = 16
     amp = float(env.dims.act_high)   # U(-1,1) (hopper/walker/cheetah) or U(-0.4,0.4) (humanoid, humanoid.xml:6)
     actions = [((torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1) * amp).cuda(local_rank).contiguous() for _ in range(nact)]
+    if args.replay:
+        # the logged transition: the state reached after a few random steps of env 0, replicated; candidates: fresh xi draws
+        for k in range(8):
+            env.step_soa(actions[k % nact])
+        q, v = env.get_state()
+        q0 = q[:1].clone().expand(B, -1).contiguous(); v0 = v[:1].clone().expand(B, -1).contiguous()
+        cands = env.sample_tasks(nact).contiguous()        # [nact, B, task_dim] on the device
+
+        def one_step(k):
+            env.set_task(cands[k % nact])                   # device-resident: no host round trip
+            env.set_state(q0, v0)
+            env.step_soa(actions[0])
+    else:
+        def one_step(k):
+            env.step_soa(actions[k % nact])
 
     def sync():
         sharding.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        env.step_soa(actions[k % nact])
-    sync()
+    # every one-time cost goes BEFORE the timed region: the HIP-event pool is created here and the warm-up launches
+    # are already timing-enabled (the first timed hipEventRecord on a stream pays a one-off profiling set-up)
+    t_setup0 = time.perf_counter()
     env.enable_timing(not args.no_kernel_timing)
+    one_step(0)
+    torch.cuda.synchronize()
+    timing_setup_ms = 1e3 * (time.perf_counter() - t_setup0)
+    for k in range(args.warmup):
+        one_step(k)
+    sync()
+    env.read_timing()                                        # drop the warm-up samples
+    counter = sharding.StepCounter(cdev, every=args.counter_every)
+    sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        env.step_soa(actions[k % nact])
+        one_step(k)
+        counter.add(B)                                       # async all-reduce every --counter-every steps (N > 1)
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = env.read_timing()
     env.enable_timing(False)
 
-    # the only collectives of the path: SUM of the step counter, MAX of the elapsed time
-    total_steps, elapsed = sharding.reduce_counter_and_time(args.steps * B, elapsed,
-                                                            torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu"))
+    # the only collectives of the path: SUM of the step counter (asynchronous, above), MAX of the elapsed time
+    total_steps = counter.total()
+    elapsed = sharding.reduce_max(elapsed, cdev)
     counters = env.counters()
 
     if rank == 0:
         value = total_steps / elapsed
-        kavg_ms = float(kernel_ms.mean()) if len(kernel_ms) else float("nan")
-        bytes_step = BYTES_PER_ENV_STEP[args.env]
+        n_k = len(kernel_ms)
+        kavg_ms = float(kernel_ms.mean()) if n_k else float("nan")
+        ksum_ms = float(kernel_ms.sum()) * (args.steps / n_k) if n_k else float("nan")
+        bytes_step = BYTES_PER_ENV_STEP[args.env] + (4 * env.task_dim if args.replay else 0)   # replay also writes xi
         achieved = bytes_step * B / (kavg_ms * 1e-3) / 1e9 if kavg_ms == kavg_ms else None
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # PMC pass result (separate rocprofv3 --pmc runs)
-        if os.path.exists(tp) and args.env == ENV_ID:
-            try:
-                traffic = json.load(open(tp)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        wall_ms = 1e3 * elapsed / args.steps
+        achieved_wall = bytes_step * B / (wall_ms * 1e-3) / 1e9
+        traffic, stale = pmc_traffic(args.env) if not args.replay else (None, False)
         out = {
             "metric": METRIC, "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, batch %d per GPU, uniform DR over the %d-dim xi (nominal +-10%%), "
-                                   "U(-%.1f,%.1f) actions, auto-reset + xi resample" % (args.env, B, env.task_dim, amp, amp),
-                       "global_batch": B * world, "parallelism": "index-sharded envs x%d, no data-path collective" % world},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_ms,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s%s, batch %d per GPU, uniform DR over the %d-dim xi (nominal +-10%%), "
+                                   "U(-%.1f,%.1f) actions, %s" % (args.env, " [replay: 1 logged transition x B candidate xi]" if args.replay else "",
+                                                                 B, env.task_dim, amp, amp,
+                                                                 "set_task + set_sim_state + step per call" if args.replay else "auto-reset + xi resample"),
+                       "global_batch": total_steps // max(args.steps, 1),
+                       "parallelism": "index-sharded envs x%d (%s scaling), no data-path collective; step counter all-reduced "
+                                      "asynchronously every %d steps" % (world, args.scaling, args.counter_every)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": KERNEL_NAME[args.env], "kernel_avg_ms": kavg_ms,
                          "algorithmic_bytes_per_launch": bytes_step * B, "bytes_per_env_step": bytes_step,
+                         # the same fraction on the WALL clock of the timed region (what `value` is computed from)
+                         "achieved_wall": achieved_wall, "frac_wall": achieved_wall / HBM_PEAK_GBS,
                          "note": "VALU-issue/latency-bound by construction (16 forward-dynamics solves per 173 B for hopper); HBM fraction reported because the metric asks for it"},
+            # wall time of the timed region minus the summed kernel time: launch + host overhead per run
+            "host_gap_ms": (1e3 * elapsed - ksum_ms) if n_k else None,
+            "timing_setup_ms": timing_setup_ms,
+            "counter_reductions": counter.reductions,
             "solver_capped_waves": counters["solver_capped"], "nonfinite_lanes": counters["nonfinite"],
         }
+        if stale:
+            out["roofline"]["traffic_note"] = "profiles/hbm_traffic.json was measured on other kernel sources (digest mismatch): re-run profiles/collect.sh"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env, B if args.env != "RandomHumanoid-v0" else 4096, args.cpu_sample_steps)
         print(json.dumps(out), flush=True)

@@ -70,6 +70,12 @@ typedef struct rex_dims {
   int discrete_action;   /* 1 for CartPole (Discrete(2), random_cartpole.py:96) */
   float dt;              /* model timestep * frame_skip, jinja_mujoco_env.py:166-168 */
   float act_low, act_high; /* actuator_ctrlrange, jinja_mujoco_env.py:99-103 */
+  int n_info;            /* per-term reward rows rex_set_info_buffer exposes: 2 for the planar chains
+                            (reward_run, reward_ctrl: random_half_cheetah.py:105-110), 4 for the humanoid
+                            (reward_linvel, reward_quadctrl, reward_alive, reward_impact: random_humanoid.py:182-187), 0 CartPole */
+  int n_aux;             /* rows of sim data that outlive a step besides (qpos, qvel): the humanoid's data.xipos[:,0]
+                            (14 bodies) left by the last mj_forward, which mass_center() reads BEFORE the next
+                            do_simulation (random_humanoid.py:22-25,162); 0 for the other chains */
 } rex_dims;
 
 /* variant: 0 = regular id, 1 = the "Unmodeled" id of the same chain (e.g. random_hopper_unmodeled.py:16-43): a
@@ -125,6 +131,28 @@ int rex_set_random_task(rex_t* h, const uint8_t* mask, void* stream);
 /* current observation of every lane (_get_obs, random_hopper.py:100-110), without noise. */
 int rex_get_obs(rex_t* h, float* obs_out, void* stream);
 
+/* The rest of the sim state get_sim_state returns (random_hopper.py:148-152: MjSimState incl. time) and the
+ * TimeLimit wrapper's elapsed-step count: per-lane step counter t [dev, int32 batch], episode index
+ * [dev, uint32 batch] (together they key the Philox streams, so restoring them makes a resume RNG-exact and
+ * time-limit-exact) and the done flags [dev, uint8 batch]. */
+int rex_get_counters_state(rex_t* h, int32_t* t, uint32_t* episode, uint8_t* done, void* stream);
+int rex_set_counters_state(rex_t* h, const int32_t* t, const uint32_t* episode, const uint8_t* done, void* stream);
+/* The remaining MjData a bit-exact resume needs (rex_dims.n_aux rows, [dev, n_aux*batch]); rex_set_state refreshes it
+ * with sim.forward() like the reference's set_state, so restore it AFTER the state. */
+int rex_get_aux(rex_t* h, float* aux, void* stream);
+int rex_set_aux(rex_t* h, const float* aux, void* stream);
+/* RandomEnv.sample_task / sample_tasks (random_env.py:145-203) WITHOUT set_task: one xi per lane into
+ * xi_out [dev, task_dim*batch]; `draw_index` selects the draw (stream family separate from the reset streams);
+ * neither the current task nor the episode counters change. */
+int rex_sample_task(rex_t* h, float* xi_out, uint64_t draw_index, void* stream);
+/* The `info` dict of step(): per-term rewards (random_half_cheetah.py:110 reward_run / reward_ctrl,
+ * random_humanoid.py:182-187 reward_linvel / reward_quadctrl / reward_alive / reward_impact) written by every
+ * later rex_step into info [dev, n_info*batch] (rex_dims.n_info rows; NULL switches it off). */
+int rex_set_info_buffer(rex_t* h, float* info);
+/* One lane's (qpos, qvel, xi) to HOST memory for an external viewer: the data MujocoEnv.render reads from the
+ * sim (jinja_mujoco_env.py:175-226; CartPole: random_cartpole.py:231-283). Synchronises the device. */
+int rex_export_lane(rex_t* h, int64_t lane, float* qpos /*[host, nq]*/, float* qvel /*[host, nv]*/, float* xi /*[host, task_dim]*/);
+
 /* number of env-steps executed by this handle (host counter; the only quantity the multi-GPU
  * path reduces across ranks). */
 int64_t rex_step_count(const rex_t* h);
@@ -133,8 +161,9 @@ int64_t rex_step_count(const rex_t* h);
  * [2] constraint solves that hit the iteration cap. Copies 4 int64 to `out` [host]; synchronises. */
 int rex_get_counters(rex_t* h, int64_t* out);
 
-/* duration in ms of the last `n` rex_step kernel launches measured with HIP events on the
- * launch stream (enabled by rex_enable_timing); returns the number of samples written. */
+/* duration in ms of the rex_step kernel launches since the last enable / read (at most the last 8192), measured
+ * with HIP events on the launch stream; returns the number of samples written.  rex_enable_timing(1) creates
+ * the event pool (the only allocation of the timing path: rex_step itself never allocates). */
 int rex_enable_timing(rex_t* h, int enable);
 int rex_read_timing(rex_t* h, float* ms_out, int max_n);
 

@@ -182,6 +182,11 @@ int mjo_humanoid_batch_step(int n, const double* qpos, const double* qvel, const
                             const double* xipos_x_prev, double* qpos_out, double* qvel_out, double* obs_out,
                             double* reward_out, unsigned char* done_out, double* xipos_x_out, int nthreads);
 
+/* Humanoid reset / set_state observation (random_humanoid.py:219-234): forward at (qpos, qvel) with the task `xi`
+ * in force (the OLD one under dr_training) and ctrl = 0.  obs_out [376][n], xipos_x_out [14][n] or NULL. */
+int mjo_humanoid_batch_reset_obs(int n, const double* qpos, const double* qvel, const double* xi, double* obs_out,
+                                 double* xipos_x_out);
+
 /* CartPole closed-form step (random_envs/random_cartpole.py:172-224) */
 void mjo_cartpole_step(const double* state, int action, const double* xi, double* next_state,
                        double* reward, int* done, int* steps_beyond_done);

@@ -94,6 +94,36 @@ int mjo_humanoid_batch_step(int n, const double* qpos, const double* qvel, const
   return 0;
 }
 
+/* Observation returned by reset() / after set_state (random_humanoid.py:219-234, jinja_mujoco_env.py:146-154):
+ * set_state(qpos, qvel) runs sim.forward() with the masses / dampings in force at that moment (`xi` here -- under
+ * dr_training these are the PREVIOUS episode's, because set_random_task comes after set_state: SURVEY Q10) and with
+ * data.ctrl = 0 (sim.reset()); _get_obs then reads qpos, qvel and the data.* fields that forward left behind. */
+int mjo_humanoid_batch_reset_obs(int n, const double* qpos, const double* qvel, const double* xi, double* obs_out,
+                                 double* xipos_x_out) {
+  mjoModel* m = (mjoModel*)malloc(sizeof(mjoModel)); mjoData* d = (mjoData*)malloc(sizeof(mjoData));
+  mjo_build_humanoid(m);
+  if (g_tol > 0) m->tolerance = g_tol;
+  for (int i = 0; i < n; i++) {
+    for (int k = 0; k < 13; k++) m->body_mass[1 + k] = xi[(size_t)k * n + i];
+    for (int k = 0; k < 17; k++) m->dof_damping[6 + k] = xi[(size_t)(13 + k) * n + i];
+    mjo_reset_data(m, d);                                              /* sim.reset(): ctrl = 0 */
+    for (int k = 0; k < 24; k++) d->qpos[k] = qpos[(size_t)k * n + i];
+    for (int k = 0; k < 23; k++) d->qvel[k] = qvel[(size_t)k * n + i];
+    mjo_forward(m, d);                                                 /* set_state -> sim.forward() */
+    mjo_com_quantities(m, d);
+    int c = 0;
+    for (int k = 2; k < 24; k++) obs_out[(size_t)(c++) * n + i] = d->qpos[k];
+    for (int k = 0; k < 23; k++) obs_out[(size_t)(c++) * n + i] = d->qvel[k];
+    for (int b = 0; b < NB; b++) for (int k = 0; k < 10; k++) obs_out[(size_t)(c++) * n + i] = d->cinert[b][k];
+    for (int b = 0; b < NB; b++) for (int k = 0; k < 6; k++) obs_out[(size_t)(c++) * n + i] = d->cvel[b][k];
+    for (int k = 0; k < 23; k++) obs_out[(size_t)(c++) * n + i] = d->qfrc_actuator[k];
+    for (int k = 0; k < 84; k++) obs_out[(size_t)(c++) * n + i] = 0.0; /* cfrc_ext, Q15 */
+    if (xipos_x_out) for (int b = 0; b < NB; b++) xipos_x_out[(size_t)b * n + i] = d->xipos[b][0];
+  }
+  free(m); free(d);
+  return 0;
+}
+
 /* compiled constants + one forward probe for tests */
 int mjo_humanoid_probe(const double* qpos, const double* qvel, const double* ctrl, const double* xi, double* body_mass,
                        double* qacc, double* qM, int* ncon, int* nefc, int* niter, double* efc_force, double* contacts, int max_con) {

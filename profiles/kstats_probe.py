@@ -1,9 +1,9 @@
 import os, sys, ctypes
 os.environ["REX_LIB"]="librex_hip_kstats.so"
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, random_envs_amd as rex
 from random_envs_amd import _native
-for eid in ["RandomHopper-v0","RandomWalker2d-v0","RandomHalfCheetah-v0"]:
+for eid in (sys.argv[1:] or ["RandomHopper-v0"]):
     B=32768
     env=rex.make(eid,batch=B,seed=0)
     nom=torch.tensor(env.original_task)

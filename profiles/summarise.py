@@ -34,8 +34,22 @@ step = [k for k in out if "planar_step_kernel" in k]
 for extra in ("bench.log", "phases.log"):   # humanoid runs (collect_humanoid.sh)
     if os.path.exists(os.path.join(P, extra)):
         shutil.copy(os.path.join(P, extra), os.path.join(ROOT, "profiles", tag + "_" + extra))
-if step and "hbm_bytes_per_launch" in out[step[0]]:
-    json.dump({"kernel": step[0], "bytes_per_launch": out[step[0]]["hbm_bytes_per_launch"]["total_corrected"],
-               "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag},
-              open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"))
+# bench.py's roofline.traffic: per env id, tied to the digest of the kernel sources that were profiled
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+try:
+    rec = json.load(open(tp))
+    if "bytes_per_launch" in rec:
+        rec = {}
+except Exception:
+    rec = {}
+for env_id, kname in bench.KERNEL_NAME.items():
+    short = kname.replace("<", "<rex::")
+    for k in out:
+        if (short in k or kname in k) and "hbm_bytes_per_launch" in out[k]:
+            rec[env_id] = {"kernel": k, "bytes_per_launch": out[k]["hbm_bytes_per_launch"]["total_corrected"],
+                           "source_digest": bench.source_digest(),
+                           "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag}
+json.dump(rec, open(tp, "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

@@ -15,6 +15,7 @@ SYMBOLS = [
     "rex_set_autoreset", "rex_seed", "rex_reset", "rex_step", "rex_get_state", "rex_set_state",
     "rex_get_task", "rex_set_task", "rex_set_random_task", "rex_get_obs", "rex_step_count",
     "rex_get_counters", "rex_enable_timing", "rex_read_timing", "rex_last_error", "rex_version",
+    "rex_get_counters_state", "rex_set_counters_state", "rex_sample_task", "rex_set_info_buffer", "rex_export_lane", "rex_get_aux", "rex_set_aux",
 ]
 
 ENV_KINDS = {"cartpole": 0, "hopper": 1, "halfcheetah": 2, "walker2d": 3, "humanoid": 4}
@@ -25,7 +26,7 @@ class RexDims(ctypes.Structure):
     _fields_ = [("nq", ctypes.c_int), ("nv", ctypes.c_int), ("act_dim", ctypes.c_int), ("obs_dim", ctypes.c_int),
                 ("task_dim", ctypes.c_int), ("frame_skip", ctypes.c_int), ("max_episode_steps", ctypes.c_int),
                 ("discrete_action", ctypes.c_int), ("dt", ctypes.c_float), ("act_low", ctypes.c_float),
-                ("act_high", ctypes.c_float)]
+                ("act_high", ctypes.c_float), ("n_info", ctypes.c_int), ("n_aux", ctypes.c_int)]
 
 
 class RexError(RuntimeError):
@@ -69,6 +70,13 @@ def lib():
     L.rex_get_counters.argtypes = [vp, ctypes.POINTER(i64)]
     L.rex_enable_timing.argtypes = [vp, i32]
     L.rex_read_timing.argtypes = [vp, fp, i32]
+    L.rex_get_counters_state.argtypes = [vp, vp, vp, vp, vp]
+    L.rex_set_counters_state.argtypes = [vp, vp, vp, vp, vp]
+    L.rex_sample_task.argtypes = [vp, vp, u64, vp]
+    L.rex_set_info_buffer.argtypes = [vp, vp]
+    L.rex_export_lane.argtypes = [vp, i64, fp, fp, fp]
+    L.rex_get_aux.argtypes = [vp, vp, vp]
+    L.rex_set_aux.argtypes = [vp, vp, vp]
     L.rex_last_error.restype = ctypes.c_char_p
     L.rex_version.restype = ctypes.c_char_p
     _lib = L

@@ -972,7 +972,7 @@ REX_HD void emit_obs(const T* qpos, const T* qvel, const Scratch<T>& s, ObsSink&
 //   obs(k, value) is called for k = 0..375 in order.
 template <class T, class ObsSink>
 REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* action, T* xipos_x, Kin<T>& K, Scratch<T>& s,
-                     T& reward, bool& done, ObsSink&& obs) {
+                     T& reward, bool& done, ObsSink&& obs, T* terms = nullptr) {
   T mt = 0, s0 = 0, s1 = 0, asq = 0;
   for (int b = 0; b < NBODY; b++) { mt += L.mass[b]; s0 += L.mass[b] * xipos_x[b]; }
   for (int u = 0; u < NU; u++) asq += action[u] * action[u];       // data.ctrl holds the raw action (:167)
@@ -980,6 +980,7 @@ REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, cons
   static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = s.obs_xipos_x[b]; s1 += L.mass[b] * xipos_x[b]; });
   const T dt = m.timestep * T(5);
   reward = T(1.25) * (s1 / mt - s0 / mt) / dt - T(0.1) * asq - T(0) /* cfrc_ext = 0, SURVEY Q15 */ + T(5);
+  if (terms) { terms[0] = T(1.25) * (s1 / mt - s0 / mt) / dt; terms[1] = -T(0.1) * asq; terms[2] = T(5); terms[3] = -T(0); }   // info dict :182-187
   done = (qpos[2] < T(1.0)) || (qpos[2] > T(2.0));                 // :173
   emit_obs(qpos, qvel, s, obs);
 }

@@ -29,6 +29,22 @@
 
 using namespace rex;
 
+// -DREX_ONLY_KIND=<rex_env_kind>: tuning builds that compile ONE chain's kernels (seconds instead of minutes);
+// the other kinds then fail in rex_create with REX_ERR_UNSUPPORTED.  The product build defines nothing.
+#ifdef REX_ONLY_KIND
+#define REX_EN_CARTPOLE (REX_ONLY_KIND == 0)
+#define REX_EN_HOPPER (REX_ONLY_KIND == 1)
+#define REX_EN_HALFCHEETAH (REX_ONLY_KIND == 2)
+#define REX_EN_WALKER2D (REX_ONLY_KIND == 3)
+#define REX_EN_HUMANOID (REX_ONLY_KIND == 4)
+#else
+#define REX_EN_CARTPOLE 1
+#define REX_EN_HOPPER 1
+#define REX_EN_HALFCHEETAH 1
+#define REX_EN_WALKER2D 1
+#define REX_EN_HUMANOID 1
+#endif
+
 #if defined(REX_KTIME)
 namespace rex { __device__ unsigned long long g_ktime[24 + 72]; }   // 0..7 planar phases, 8..23 humanoid phases, 24.. histogram of humanoid row counts
 extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build only (not in rex.h)
@@ -85,8 +101,12 @@ struct DRParams {
   const float* chol;        // fullgaussian: lower Cholesky factor of cov, row-major [dim][MAX_XI], DEVICE memory
 };
 
-constexpr unsigned long long EP_STRIDE = 1ull << 16;   // Philox offsets per episode
+// Philox offsets per episode: [0, 256) init-state noise, [256, 512) xi draws, STEP_BASE + t * STEP_STRIDE the
+// observation noise of step t.  2^32 offsets per episode keep the step regions of consecutive episodes disjoint for
+// 2^26 steps (time_limit off / endless episodes run far past 500 steps); the Philox counter is 64-bit + 64-bit subsequence.
+constexpr unsigned long long EP_STRIDE = 1ull << 32;
 constexpr unsigned long long STEP_BASE = 512, STEP_STRIDE = 64;
+constexpr unsigned long long SAMPLE_SEED_SALT = 0x9E3779B97F4A7C15ull;   // rex_sample_task: a stream family of its own
 
 // truncated standard normal on [-2, 2] by inverse CDF (the method scipy.stats.truncnorm.rvs uses)
 __device__ __forceinline__ float truncnorm2(float u) {
@@ -149,6 +169,7 @@ struct DevState {
 struct StepFlags {
   int endless, noisy, time_limit, max_steps;
   float noise_std;
+  float* info;   // optional per-term reward rows [n_info][B] (random_half_cheetah.py:110, random_humanoid.py:182-187); null = off
 };
 
 // ------------------------------------------------------------------------------------------
@@ -313,6 +334,7 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; (term_obs + (size_t)k * B)[i] = (obs + (size_t)k * B)[i]; });
   reward[i] = r; done_out[i] = d ? 1 : 0;
   if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+  if (fl.info) { fl.info[i] = dx / dt; (fl.info + (size_t)B)[i] = -S::CTRL_COST * asq; }   // info: reward_run, reward_ctrl (random_half_cheetah.py:105-110)
   // auto-reset fused into the step launch: finished lanes restart here (saves the masked reset launch and
   // the kernel boundary, ~10 % of a hopper step at B = 32768)
 #if defined(REX_WAVETIME)
@@ -366,6 +388,7 @@ __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags 
   planar_reset_lane<S>(s, fl, dr, resample, reset_state, i, obs);
 }
 
+#if REX_EN_WALKER2D
 // walker2d: re-derive the per-env model constants from the xi lengths for the masked lanes
 // (replaces build_model() inside RandomWalker2dEnv.set_task, random_walker2d.py:106-113).
 __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit,
@@ -385,6 +408,8 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
   // masses 1..3 become the geometry-derived ones of the new lengths (random_walker2d_unmodeled.py:109-116)
   if (refresh_frozen_masses) for (int b = 0; b < 3; b++) (s.xi + (size_t)b * s.B)[i] = (float)nominal[b];
 }
+
+#endif
 
 template <class S>
 __global__ void __launch_bounds__(64) planar_obs_kernel(DevState s, float* __restrict__ obs) {
@@ -412,6 +437,7 @@ __global__ void fill_rows_kernel(float* dst, const float* vals, int nrows, long 
 // lives in HIP scratch memory, lane-interleaved so every access of a wave is one coalesced segment.
 // The compiled model is uniform and sits in __constant__ memory.
 // ------------------------------------------------------------------------------------------
+#if REX_EN_HUMANOID
 __constant__ hum::Model<float> c_hum;
 
 __device__ __forceinline__ void hum_lane(const DevState& s, unsigned i, hum::Lane<float>& L) {
@@ -447,12 +473,14 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
 #if defined(REX_WAVETIME)
   const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
 #endif
+  float terms[4];
   hum::env_step(c_hum, L, q, v, a, xp, kn, sc, r, dn, [&](int k, float val) {
     // noise only on the qpos / qvel slices (random_humanoid.py:193-204)
     if (fl.noisy && k < 45) val += fl.noise_std * rocrand_normal(&st);
     (obs + k * B)[i] = val;
     if (term_obs) (term_obs + k * B)[i] = val;
-  });
+  }, terms);
+  if (fl.info) for (int k = 0; k < 4; k++) (fl.info + k * B)[i] = terms[k];   // reward_linvel, _quadctrl, _alive, _impact (random_humanoid.py:182-187)
 #if defined(REX_WAVETIME)
   if ((threadIdx.x & 63) == 0) g_wavetime[blockIdx.x & 8191] = __builtin_amdgcn_s_memtime() - tk0;
 #endif
@@ -532,6 +560,8 @@ __global__ void __launch_bounds__(64) humanoid_forward_kernel(DevState s, float*
   for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
 }
 
+#endif  // REX_EN_HUMANOID
+
 // ------------------------------------------------------------------------------------------
 // host-side handle
 // ------------------------------------------------------------------------------------------
@@ -554,26 +584,28 @@ struct rex_env {
   int full_dim = 0;                 // rows of the full xi block (dims.task_dim = rows exposed as the task)
   float* d_scratch = nullptr;   // MAX_XI floats
   float* d_chol = nullptr;      // MAX_XI*MAX_XI floats (fullgaussian Cholesky factor)
-  // timing
+  int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
+  // timing: event pool created by rex_enable_timing, used as a ring by rex_step (no allocation in the step path)
   int timing = 0;
   std::vector<hipEvent_t> ev0, ev1;
-  size_t ev_n = 0;
+  size_t ev_n = 0;              // launches recorded since the last enable / read
 };
+constexpr size_t EV_POOL = 8192;
 
 static int fill_dims(int kind, int variant, rex_dims* d) {
   memset(d, 0, sizeof *d);
   d->max_episode_steps = 500;                 // every gym.envs.register call, e.g. random_hopper.py:155-166
   int rc = -1;
   switch (kind) {
-    case REX_CARTPOLE:    d->nq = 2; d->nv = 2; d->act_dim = 1; d->obs_dim = 4; d->task_dim = 4; d->frame_skip = 1;
+    case REX_CARTPOLE:    d->nq = 2; d->nv = 2; d->act_dim = 1; d->obs_dim = 4; d->task_dim = 4; d->frame_skip = 1; d->n_info = 0;
                           d->discrete_action = 1; d->dt = 0.02f; d->act_low = 0; d->act_high = 1; rc = 0; break;
-    case REX_HOPPER:      d->nq = 6; d->nv = 6; d->act_dim = 3; d->obs_dim = 11; d->task_dim = 4; d->frame_skip = 4;
+    case REX_HOPPER:      d->nq = 6; d->nv = 6; d->act_dim = 3; d->obs_dim = 11; d->task_dim = 4; d->frame_skip = 4; d->n_info = 2;
                           d->dt = 0.008f; d->act_low = -1; d->act_high = 1; rc = 0; break;
-    case REX_HALFCHEETAH: d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 8; d->frame_skip = 5;
+    case REX_HALFCHEETAH: d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 8; d->frame_skip = 5; d->n_info = 2;
                           d->dt = 0.05f; d->act_low = -1; d->act_high = 1; rc = 0; break;
-    case REX_WALKER2D:    d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 13; d->frame_skip = 4;
+    case REX_WALKER2D:    d->nq = 9; d->nv = 9; d->act_dim = 6; d->obs_dim = 17; d->task_dim = 13; d->frame_skip = 4; d->n_info = 2;
                           d->dt = 0.008f; d->act_low = -1; d->act_high = 1; rc = 0; break;
-    case REX_HUMANOID:    d->nq = 24; d->nv = 23; d->act_dim = 17; d->obs_dim = 376; d->task_dim = 30; d->frame_skip = 5;
+    case REX_HUMANOID:    d->nq = 24; d->nv = 23; d->act_dim = 17; d->obs_dim = 376; d->task_dim = 30; d->frame_skip = 5; d->n_info = 4; d->n_aux = 14;
                           d->dt = 0.015f; d->act_low = -0.4f; d->act_high = 0.4f; rc = 0; break;   // humanoid.xml:6,9; random_humanoid.py:41
     default: return -1;
   }
@@ -639,13 +671,17 @@ static int lanes_for(long long B) {
   return B >= 65536 ? 64 : 32;
 }
 // dynamic LDS of the humanoid kernels: one dual-PGS column (hum::DUAL_WORDS floats) per lane
-static size_t hum_lds_bytes(long long B) { return sizeof(float) * hum::DUAL_WORDS * (size_t)lanes_for(B); }
-static unsigned grid_for(long long B) { int l = lanes_for(B); return (unsigned)((B + l - 1) / l); }
+// (read once in rex_create and cached in the handle: grid, block and dynamic-LDS size always agree)
+static size_t hum_lds_bytes(const rex_env* h) { return sizeof(float) * hum::DUAL_WORDS * (size_t)h->lanes; }
+static unsigned grid_for(const rex_env* h) { return (unsigned)((h->B + h->lanes - 1) / h->lanes); }
+static unsigned lanes_of(const rex_env* h) { return (unsigned)h->lanes; }
 
 static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st, int task_changed) {
-  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), 0, st, h->dev, mask, bit,
+#if REX_EN_WALKER2D
+  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, h->dev, mask, bit,
                      (h->variant && task_changed) ? 1 : 0);
   HIP_TRY(hipGetLastError());
+#endif
   return REX_OK;
 }
 
@@ -656,13 +692,18 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   rex_dims dims, full;
   if (fill_dims(env_kind, variant, &dims) || fill_dims(env_kind, 0, &full))
     return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
+#ifdef REX_ONLY_KIND
+  if (env_kind != REX_ONLY_KIND) return set_err(REX_ERR_UNSUPPORTED, "this tuning build holds env kind %d only", (int)REX_ONLY_KIND);
+#endif
   HIP_TRY(hipSetDevice(device_id));
   rex_env* h = new (std::nothrow) rex_env();
   if (!h) return set_err(REX_ERR_ARG, "out of host memory");
   h->kind = env_kind; h->variant = variant; h->device = device_id; h->B = batch; h->env_offset = env_offset; h->seed = seed;
+  h->lanes = lanes_for(batch);
+  if (h->lanes < 8 || h->lanes > 64 || (h->lanes & (h->lanes - 1))) { int l = h->lanes; delete h; return set_err(REX_ERR_ARG, "REX_LANES must be 8, 16, 32 or 64 (got %d)", l); }
   h->dims = dims;
   h->flags.endless = 0; h->flags.noisy = 0; h->flags.time_limit = 1; h->flags.max_steps = dims.max_episode_steps;
-  h->flags.noise_std = 0.0f;
+  h->flags.noise_std = 0.0f; h->flags.info = nullptr;
   h->full_dim = full.task_dim;
   h->dr.type = REX_DR_NONE; h->dr.dim = dims.task_dim;
   variant_map(env_kind, variant, full.task_dim, h->dr.map);
@@ -705,6 +746,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       h->nominal_xi[11] = 0.9f; h->nominal_xi[12] = 1.9f;                                                                // random_walker2d.py:37
       HIP_TRY(hipMalloc(&d.geom, sizeof(float) * kWalkerCompact * B));
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
+#if REX_EN_HUMANOID
     case REX_HUMANOID: {
       static hum::Model<double> md; static hum::Model<float> mf; static bool built = false;
       if (!built) {
@@ -731,6 +773,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       HIP_TRY(hipMemset(d.aux, 0, sizeof(float) * hum::NBODY * B));
       noise_var = 1e-3f;                                                                      // :39
       break; }
+#endif
   }
   h->flags.noise_std = sqrtf(noise_var);
   if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
@@ -741,15 +784,17 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);
   HIP_TRY(hipGetLastError());
   if (env_kind == REX_WALKER2D) { int rc = launch_walker_derive(h, nullptr, 0, 0, 0); if (rc) return rc; }
+#if REX_EN_HUMANOID
   if (env_kind == REX_HUMANOID) {
     float q0[MAX_XI] = {0}; q0[2] = 1.4f; q0[3] = 1.0f;                                       // humanoid.xml:30,32
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->d_scratch, q0, sizeof(float) * dims.nq, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.qpos, h->d_scratch, dims.nq, (long long)B);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), hum_lds_bytes(h->B), 0, h->dev, (float*)nullptr);
+    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), 0, h->dev, (float*)nullptr);
     HIP_TRY(hipGetLastError());
   }
+#endif
   if (env_kind == REX_HOPPER || env_kind == REX_WALKER2D) {
     float q0[MAX_XI] = {0}; q0[1] = 1.25f;
     HIP_TRY(hipDeviceSynchronize());
@@ -816,15 +861,25 @@ extern "C" int rex_set_autoreset(rex_t* h, int autoreset, int time_limit) {
 extern "C" int rex_seed(rex_t* h, uint64_t seed) { if (!h) return set_err(REX_ERR_ARG, "null handle"); h->seed = seed; h->dev.seed = seed; return REX_OK; }
 
 static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, int reset_state, float* obs, hipStream_t st) {
-  const dim3 g(grid_for(h->B)), b(lanes_for(h->B));
+  const dim3 g(grid_for(h)), b(lanes_of(h));
   if (resample && h->dr.type == REX_DR_NONE) return set_err(REX_ERR_STATE,
       "sampling value of random env needs to be set before using sample_task() or set_random_task()");   // random_env.py:201
   switch (h->kind) {
+#if REX_EN_CARTPOLE
     case REX_CARTPOLE: hipLaunchKernelGGL(cartpole_reset_kernel, g, b, 0, st, h->dev, h->dr, resample, reset_state, mask, bit, obs); break;
+#endif
+#if REX_EN_HOPPER
     case REX_HOPPER: hipLaunchKernelGGL(planar_reset_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+#endif
+#if REX_EN_HALFCHEETAH
     case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_reset_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+#endif
+#if REX_EN_WALKER2D
     case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
-    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_reset_kernel, g, b, hum_lds_bytes(h->B), st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+#endif
+#if REX_EN_HUMANOID
+    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_reset_kernel, g, b, hum_lds_bytes(h), st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+#endif
   }
   HIP_TRY(hipGetLastError());
   if (h->kind == REX_WALKER2D && resample) return launch_walker_derive(h, mask, bit, st, 1);
@@ -849,30 +904,37 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   if (!h) return set_err(REX_ERR_ARG, "null handle");
   if (!action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_step: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g(grid_for(h->B)), b(lanes_for(h->B));
+  HIP_TRY(hipSetDevice(h->device));
+  const dim3 g(grid_for(h)), b(lanes_of(h));
   const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
   // planar envs reset finished lanes inside the step kernel; walker2d with DR needs the separate derive launch
   const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH ||
                                       (h->kind == REX_WALKER2D && !(resample_on_reset && h->dr.type != REX_DR_NONE)))) ? 1 : 0;
-  if (h->timing) {
-    if (h->ev_n >= h->ev0.size()) {
-      hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
-    }
-    HIP_TRY(hipEventRecord(h->ev0[h->ev_n], st));
-  }
+  const size_t ev_slot = h->ev_n % EV_POOL;   // ring over the pool rex_enable_timing created
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
   switch (h->kind) {
+#if REX_EN_CARTPOLE
     case REX_CARTPOLE:
       hipLaunchKernelGGL(cartpole_step_kernel, g, b, 0, st, h->dev, h->flags, (const int*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+#endif
+#if REX_EN_HOPPER
     case REX_HOPPER:
       hipLaunchKernelGGL(planar_step_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->g_hopper, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
+#endif
+#if REX_EN_HALFCHEETAH
     case REX_HALFCHEETAH:
       hipLaunchKernelGGL(planar_step_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->g_cheetah, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
+#endif
+#if REX_EN_WALKER2D
     case REX_WALKER2D:
       hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
+#endif
+#if REX_EN_HUMANOID
     case REX_HUMANOID:
-      hipLaunchKernelGGL(humanoid_step_kernel, g, b, hum_lds_bytes(h->B), st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+      hipLaunchKernelGGL(humanoid_step_kernel, g, b, hum_lds_bytes(h), st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+#endif
   }
-  if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[h->ev_n], st)); h->ev_n++; }
+  if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
   HIP_TRY(hipGetLastError());
   h->step_count += h->B;
   if (h->autoreset && !fused) return do_reset(h, h->dev.done, 2, resample_on_reset, 1, obs_out, st);
@@ -893,10 +955,12 @@ extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, voi
   int rc = copy_rows(h->dev.qpos, qpos, h->dims.nq, h->B, (hipStream_t)stream); if (rc) return rc;
   rc = copy_rows(h->dev.qvel, qvel, h->dims.nv, h->B, (hipStream_t)stream); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(h->dev.done, 0, (size_t)h->B, (hipStream_t)stream));   // steps_beyond_done = None
+#if REX_EN_HUMANOID
   if (h->kind == REX_HUMANOID) {   // set_state runs sim.forward(): refreshes data.xipos (jinja_mujoco_env.py:154)
-    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h->B)), dim3(lanes_for(h->B)), hum_lds_bytes(h->B), (hipStream_t)stream, h->dev, (float*)nullptr);
+    hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), (hipStream_t)stream, h->dev, (float*)nullptr);
     HIP_TRY(hipGetLastError());
   }
+#endif
   return REX_OK;
 }
 extern "C" int rex_get_task(rex_t* h, float* xi, void* stream) {
@@ -909,21 +973,33 @@ extern "C" int rex_get_task(rex_t* h, float* xi, void* stream) {
 extern "C" int rex_set_task(rex_t* h, const float* xi, void* stream) {
   if (!h || !xi) return set_err(REX_ERR_ARG, "rex_set_task: null argument");
   int rc = REX_OK;
-  for (int k = 0; k < h->dims.task_dim; k++) {
+  if (!h->variant) rc = copy_rows(h->dev.xi, xi, h->dims.task_dim, h->B, (hipStream_t)stream);   // identity map: one copy
+  else for (int k = 0; k < h->dims.task_dim; k++) {
     rc = copy_rows(h->dev.xi + (size_t)h->dr.map[k] * h->B, xi + (size_t)k * h->B, 1, h->B, (hipStream_t)stream); if (rc) return rc;
   }
+  if (rc) return rc;
   if (h->kind == REX_WALKER2D) return launch_walker_derive(h, nullptr, 0, (hipStream_t)stream, 1);
   return REX_OK;
 }
 extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
   if (!h || !obs_out) return set_err(REX_ERR_ARG, "rex_get_obs: null argument");
-  const dim3 g(grid_for(h->B)), b(lanes_for(h->B)); hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid_for(h)), b(lanes_of(h)); hipStream_t st = (hipStream_t)stream;
   switch (h->kind) {
+#if REX_EN_CARTPOLE
     case REX_CARTPOLE: hipLaunchKernelGGL(cartpole_obs_kernel, g, b, 0, st, h->dev, obs_out); break;
+#endif
+#if REX_EN_HOPPER
     case REX_HOPPER: hipLaunchKernelGGL(planar_obs_kernel<HopperSpec>, g, b, 0, st, h->dev, obs_out); break;
+#endif
+#if REX_EN_HALFCHEETAH
     case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_obs_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, obs_out); break;
+#endif
+#if REX_EN_WALKER2D
     case REX_WALKER2D: hipLaunchKernelGGL(planar_obs_kernel<Walker2dSpec>, g, b, 0, st, h->dev, obs_out); break;
-    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_forward_kernel, g, b, hum_lds_bytes(h->B), st, h->dev, obs_out); break;
+#endif
+#if REX_EN_HUMANOID
+    case REX_HUMANOID: hipLaunchKernelGGL(humanoid_forward_kernel, g, b, hum_lds_bytes(h), st, h->dev, obs_out); break;
+#endif
   }
   HIP_TRY(hipGetLastError());
   return REX_OK;
@@ -939,17 +1015,93 @@ extern "C" int rex_get_counters(rex_t* h, int64_t* out) {
 }
 extern "C" int rex_enable_timing(rex_t* h, int enable) {
   if (!h) return set_err(REX_ERR_ARG, "null handle");
+  if (enable && h->ev0.empty()) {   // the only place events are created: rex_step never allocates
+    HIP_TRY(hipSetDevice(h->device));
+    h->ev0.reserve(EV_POOL); h->ev1.reserve(EV_POOL);
+    for (size_t k = 0; k < EV_POOL; k++) {
+      hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
+    }
+  }
   h->timing = enable ? 1 : 0; h->ev_n = 0;
   return REX_OK;
 }
 extern "C" int rex_read_timing(rex_t* h, float* ms_out, int max_n) {
   if (!h || !ms_out) { set_err(REX_ERR_ARG, "rex_read_timing: null argument"); return REX_ERR_ARG; }
   int n = 0;
-  for (size_t k = 0; k < h->ev_n && n < max_n; k++) {
-    if (hipEventSynchronize(h->ev1[k]) != hipSuccess) break;
-    float ms = 0; if (hipEventElapsedTime(&ms, h->ev0[k], h->ev1[k]) != hipSuccess) break;
+  const size_t first = h->ev_n > EV_POOL ? h->ev_n - EV_POOL : 0;   // the ring keeps the last EV_POOL launches
+  for (size_t k = first; k < h->ev_n && n < max_n; k++) {
+    const size_t slot = k % EV_POOL;
+    if (hipEventSynchronize(h->ev1[slot]) != hipSuccess) break;
+    float ms = 0; if (hipEventElapsedTime(&ms, h->ev0[slot], h->ev1[slot]) != hipSuccess) break;
     ms_out[n++] = ms;
   }
   h->ev_n = 0;
   return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// episode bookkeeping, lane export, side-effect-free xi draws
+// ------------------------------------------------------------------------------------------
+extern "C" int rex_get_counters_state(rex_t* h, int32_t* t, uint32_t* episode, uint8_t* done, void* stream) {
+  if (!h || !t || !episode || !done) return set_err(REX_ERR_ARG, "rex_get_counters_state: null argument");
+  hipStream_t st = (hipStream_t)stream; const size_t B = (size_t)h->B;
+  HIP_TRY(hipMemcpyAsync(t, h->dev.t, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(episode, h->dev.episode, sizeof(unsigned) * B, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(done, h->dev.done, B, hipMemcpyDeviceToDevice, st));
+  return REX_OK;
+}
+extern "C" int rex_set_counters_state(rex_t* h, const int32_t* t, const uint32_t* episode, const uint8_t* done, void* stream) {
+  if (!h || !t || !episode || !done) return set_err(REX_ERR_ARG, "rex_set_counters_state: null argument");
+  hipStream_t st = (hipStream_t)stream; const size_t B = (size_t)h->B;
+  HIP_TRY(hipMemcpyAsync(h->dev.t, t, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->dev.episode, episode, sizeof(unsigned) * B, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(h->dev.done, done, B, hipMemcpyDeviceToDevice, st));
+  return REX_OK;
+}
+extern "C" int rex_get_aux(rex_t* h, float* aux, void* stream) {
+  if (!h || !aux) return set_err(REX_ERR_ARG, "rex_get_aux: null argument");
+  if (!h->dims.n_aux) return set_err(REX_ERR_UNSUPPORTED, "this env kind keeps no auxiliary sim data");
+  return copy_rows(aux, h->dev.aux, h->dims.n_aux, h->B, (hipStream_t)stream);
+}
+extern "C" int rex_set_aux(rex_t* h, const float* aux, void* stream) {
+  if (!h || !aux) return set_err(REX_ERR_ARG, "rex_set_aux: null argument");
+  if (!h->dims.n_aux) return set_err(REX_ERR_UNSUPPORTED, "this env kind keeps no auxiliary sim data");
+  return copy_rows(h->dev.aux, aux, h->dims.n_aux, h->B, (hipStream_t)stream);
+}
+extern "C" int rex_set_info_buffer(rex_t* h, float* info) {
+  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  if (info && h->dims.n_info == 0) return set_err(REX_ERR_UNSUPPORTED, "this env kind has no per-term reward info");
+  h->flags.info = info;
+  return REX_OK;
+}
+extern "C" int rex_export_lane(rex_t* h, int64_t lane, float* qpos, float* qvel, float* xi) {
+  if (!h || !qpos || !qvel || !xi) return set_err(REX_ERR_ARG, "rex_export_lane: null argument");
+  if (lane < 0 || lane >= h->B) return set_err(REX_ERR_ARG, "rex_export_lane: lane %lld outside [0, %lld)", (long long)lane, h->B);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t B = (size_t)h->B;   // SoA rows: element `lane` of every row (a strided 2-D copy)
+  HIP_TRY(hipMemcpy2D(qpos, sizeof(float), h->dev.qpos + lane, sizeof(float) * B, sizeof(float), h->dims.nq, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(qvel, sizeof(float), h->dev.qvel + lane, sizeof(float) * B, sizeof(float), h->dims.nv, hipMemcpyDeviceToHost));
+  for (int k = 0; k < h->dims.task_dim; k++)
+    HIP_TRY(hipMemcpy(xi + k, h->dev.xi + (size_t)h->dr.map[k] * B + lane, sizeof(float), hipMemcpyDeviceToHost));
+  return REX_OK;
+}
+
+// RandomEnv.sample_task (random_env.py:148-203) for every lane WITHOUT applying it (no episode bump, xi untouched):
+// draw `draw_index` of a stream family of its own, into the caller's [task_dim][batch] buffer.
+__global__ void __launch_bounds__(64) sample_task_kernel(DevState s, DRParams dr, unsigned long long draw_index, float* __restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.B) return;
+  sample_task(dr, s.seed ^ SAMPLE_SEED_SALT, (unsigned long long)(s.env_offset + i), draw_index * 256ull, out, (size_t)s.B, i, s.counters);
+}
+extern "C" int rex_sample_task(rex_t* h, float* xi_out, uint64_t draw_index, void* stream) {
+  if (!h || !xi_out) return set_err(REX_ERR_ARG, "rex_sample_task: null argument");
+  if (h->dr.type == REX_DR_NONE) return set_err(REX_ERR_STATE,
+      "sampling value of random env needs to be set before using sample_task() or set_random_task()");   // random_env.py:201
+  HIP_TRY(hipSetDevice(h->device));
+  DRParams dr = h->dr;
+  for (int k = 0; k < dr.dim; k++) dr.map[k] = k;   // task order, not the kernels' full xi block
+  hipLaunchKernelGGL(sample_task_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, (hipStream_t)stream, h->dev, dr, (unsigned long long)draw_index, xi_out);
+  HIP_TRY(hipGetLastError());
+  return REX_OK;
 }

@@ -40,11 +40,33 @@ class SB3VecEnvAdapter:
     def seed(self, seed=None):
         return self.env.seed(seed)
 
+    def _n(self, indices):
+        if indices is None:
+            return self.num_envs
+        return 1 if isinstance(indices, int) else len(list(indices))
+
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        return [getattr(self.env, method_name)(*args, **kwargs)]
+        """SB3 expects one result per (selected) env; the batch is ONE object, so the call runs once and its result
+        is repeated.  Batched results ([num_envs, ...] tensors) are split per env instead."""
+        out = getattr(self.env, method_name)(*args, **kwargs)
+        n = self._n(indices)
+        if hasattr(out, "shape") and len(out.shape) >= 1 and out.shape[0] == self.num_envs:
+            idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+            return [out[i] for i in idx]
+        return [out] * n
 
     def get_attr(self, attr_name, indices=None):
-        return [getattr(self.env, attr_name)]
+        return [getattr(self.env, attr_name)] * self._n(indices)
 
     def set_attr(self, attr_name, value, indices=None):
         setattr(self.env, attr_name, value)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self._n(indices)
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def export_lane(self, k=0):
+        """Host snapshot (qpos, qvel, xi) of env k for an external viewer (rendering stays off the GPU path)."""
+        return self.env.export_lane(k)

@@ -57,6 +57,62 @@ def reduce_counter_and_time(steps_done, elapsed_s, device):
     return int(c.item()), float(t.item())
 
 
+class StepCounter:
+    """The path's ONLY collective: the global env-step counter, summed over ranks
+    asynchronously every `every` steps so it never sits on the step critical path.  `add()` is called once per
+    batched step; every `every`-th call snapshots the local count into a staging tensor and issues
+    ``all_reduce(SUM, async_op=True)`` (RCCL runs it on its own stream; gloo on its worker thread); the previous
+    reduction is waited for only when the next one is issued.  `total()` drains and returns the exact global
+    count.  At world size 1 it is a plain integer."""
+
+    def __init__(self, device, every=256):
+        import torch
+        import torch.distributed as dist
+        self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.every = max(int(every), 1)
+        self.local = 0            # env-steps of this rank
+        self.n_calls = 0
+        self.last_global = 0      # most recent completed global sum (lags by < 2 * every steps)
+        self._work = None
+        self._buf = torch.zeros(1, dtype=torch.int64, device=device)
+        self.reductions = 0
+
+    def add(self, env_steps):
+        self.local += int(env_steps)
+        self.n_calls += 1
+        if self._dist is not None and self.n_calls % self.every == 0:
+            self._issue()
+
+    def _issue(self):
+        self._drain()
+        self._buf.fill_(self.local)
+        self._work = self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, async_op=True)
+        self.reductions += 1
+
+    def _drain(self):
+        if self._work is not None:
+            self._work.wait()
+            self.last_global = int(self._buf.item())
+            self._work = None
+
+    def total(self):
+        if self._dist is None:
+            return self.local
+        self._issue()
+        self._drain()
+        return self.last_global
+
+
+def reduce_max(value, device):
+    """MAX over ranks of a host float (the elapsed time of the bench contract)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def shutdown():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -131,5 +131,4 @@ IDS = {
     "RandomHumanoidUnmodeled-v0": ("humanoid", {"unmodeled": True}),         # random_humanoid_unmodeled.py:275-279
 }
 # ids of the reference not built yet: none (all 13 ids of SURVEY.md Appendix A are registered)
-PENDING_IDS = []
 MAX_EPISODE_STEPS = 500

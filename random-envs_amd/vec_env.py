@@ -68,7 +68,20 @@ class VecRandomEnv(DRConfig):
         self._trunc = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self._act = torch.zeros(dims.act_dim, B, dtype=torch.int32 if dims.discrete_action else torch.float32,
                                 device=self.device)
+        self._info = torch.zeros(max(dims.n_info, 1), B, **f32) if dims.n_info else None
+        if self._info is not None:
+            _native.check(L.rex_set_info_buffer(self._h, ctypes.c_void_p(self._info.data_ptr())))
+        self._draws = 0
         self._push_flags()
+
+    @property
+    def dt(self):                             # jinja_mujoco_env.py:166-168: model.opt.timestep * frame_skip
+        return float(self.dims.dt)
+
+    #: names of the per-term reward rows returned in ``info`` (random_half_cheetah.py:110, random_humanoid.py:182-187)
+    INFO_TERMS = {"hopper": ("reward_run", "reward_ctrl"), "walker2d": ("reward_run", "reward_ctrl"),
+                  "halfcheetah": ("reward_run", "reward_ctrl"),
+                  "humanoid": ("reward_linvel", "reward_quadctrl", "reward_alive", "reward_impact"), "cartpole": ()}
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -122,13 +135,17 @@ class VecRandomEnv(DRConfig):
         return self.sample_tasks(1)[0]
 
     def sample_tasks(self, num_tasks=1):      # random_env.py:145-146
-        keep = self.get_task().clone()
-        out = []
-        for _ in range(num_tasks):
-            self.set_random_task()
-            out.append(self.get_task().clone())
-        self.set_task(keep)
-        return self._torch.stack(out)
+        """[num_tasks, batch, task_dim] draws from the DR distribution.  Side-effect free like the reference's:
+        neither the current task nor the episode counters (which key the reset streams) change."""
+        if self.sampling is None:
+            raise ValueError('sampling value of random env needs to be set before using sample_task() or '
+                             'set_random_task(). Set it by uploading a DR distr.')
+        t = self._torch
+        out = t.empty(num_tasks, self.task_dim, self.batch, dtype=t.float32, device=self.device)
+        for k in range(num_tasks):
+            _native.check(self._L.rex_sample_task(self._h, ctypes.c_void_p(out[k].data_ptr()), self._draws, self._stream()))
+            self._draws += 1
+        return out.transpose(1, 2)
 
     # ------------------------------------------------------------------ task / state
     def get_task(self):
@@ -137,18 +154,21 @@ class VecRandomEnv(DRConfig):
         return xi.t()
 
     def set_task(self, *task):
-        """set_task(xi[batch, task_dim]) or set_task(*xi_scalars) broadcast to every env."""
+        """set_task(xi[batch, task_dim]) or set_task(*xi_scalars) broadcast to every env.  A tensor already on the
+        env's device stays there (no host round trip, no synchronisation): the replay workload sets a fresh xi per
+        call."""
         t = self._torch
-        if len(task) == 1 and hasattr(task[0], "__len__"):
-            x = t.as_tensor(np.asarray(task[0].cpu() if hasattr(task[0], "cpu") else task[0]), dtype=t.float32)
+        if len(task) == 1 and isinstance(task[0], t.Tensor):
+            x = task[0].to(device=self.device, dtype=t.float32)
+        elif len(task) == 1 and hasattr(task[0], "__len__"):
+            x = t.as_tensor(np.asarray(task[0], dtype=np.float32)).to(self.device)
         else:
-            x = t.as_tensor(np.asarray(task, dtype=np.float32))
+            x = t.as_tensor(np.asarray(task, dtype=np.float32)).to(self.device)
         if x.dim() == 1:
             x = x.unsqueeze(0).expand(self.batch, -1)
         assert tuple(x.shape) == (self.batch, self.task_dim), "task must be [batch, task_dim]"
-        xi = x.t().contiguous().to(self.device)
-        _native.check(self._L.rex_set_task(self._h, ctypes.c_void_p(xi.data_ptr()), self._stream()))
-        t.cuda.current_stream(self.device).synchronize()
+        self._xi_in = x.t().contiguous()      # kept alive until the next call (the copy is stream-ordered)
+        _native.check(self._L.rex_set_task(self._h, ctypes.c_void_p(self._xi_in.data_ptr()), self._stream()))
 
     def get_state(self):
         t = self._torch
@@ -162,10 +182,52 @@ class VecRandomEnv(DRConfig):
         q = t.as_tensor(qpos, dtype=t.float32).reshape(-1, self.dims.nq)
         v = t.as_tensor(qvel, dtype=t.float32).reshape(-1, self.dims.nv)
         assert q.shape[0] in (1, self.batch)
-        q = q.expand(self.batch, -1).t().contiguous().to(self.device)
-        v = v.expand(self.batch, -1).t().contiguous().to(self.device)
-        _native.check(self._L.rex_set_state(self._h, ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(v.data_ptr()), self._stream()))
-        t.cuda.current_stream(self.device).synchronize()
+        self._q_in = q.to(self.device).expand(self.batch, -1).t().contiguous()
+        self._v_in = v.to(self.device).expand(self.batch, -1).t().contiguous()
+        _native.check(self._L.rex_set_state(self._h, ctypes.c_void_p(self._q_in.data_ptr()), ctypes.c_void_p(self._v_in.data_ptr()), self._stream()))
+
+    def get_full_state(self):
+        """Everything a bit-exact resume needs (the reference's MjSimState carries time as well, random_hopper.py:
+        148-152; gym's TimeLimit its elapsed steps): qpos, qvel, xi and the per-lane step / episode counters that
+        key the Philox streams, plus the done flags."""
+        t = self._torch
+        q, v = self.get_state()
+        B = self.batch
+        tt = t.empty(B, dtype=t.int32, device=self.device)
+        ep = t.empty(B, dtype=t.int32, device=self.device)      # uint32 bit pattern
+        dn = t.empty(B, dtype=t.uint8, device=self.device)
+        _native.check(self._L.rex_get_counters_state(self._h, ctypes.c_void_p(tt.data_ptr()), ctypes.c_void_p(ep.data_ptr()),
+                                                     ctypes.c_void_p(dn.data_ptr()), self._stream()))
+        st = dict(qpos=q.clone(), qvel=v.clone(), task=self.get_task().clone(), t=tt, episode=ep, done=dn)
+        if self.dims.n_aux:   # humanoid: data.xipos[:, 0] of the last mj_forward (mass_center() "before", random_humanoid.py:162)
+            aux = t.empty(self.dims.n_aux, B, dtype=t.float32, device=self.device)
+            _native.check(self._L.rex_get_aux(self._h, ctypes.c_void_p(aux.data_ptr()), self._stream()))
+            st["aux"] = aux
+        return st
+
+    def set_full_state(self, st):
+        """Inverse of :meth:`get_full_state`.  Order matters for the humanoid: set_state runs sim.forward() with the
+        masses in force, so the task goes first (the same order get_full_state observed them in)."""
+        self.set_task(st["task"])
+        self.set_state(st["qpos"], st["qvel"])
+        keep = [st[k].to(self.device).contiguous() for k in ("t", "episode", "done")]
+        if self.dims.n_aux and "aux" in st:   # after set_state (whose sim.forward() refreshes it)
+            keep.append(st["aux"].to(self.device).contiguous())
+            _native.check(self._L.rex_set_aux(self._h, ctypes.c_void_p(keep[3].data_ptr()), self._stream()))
+        self._ctr_in = keep
+        _native.check(self._L.rex_set_counters_state(self._h, ctypes.c_void_p(keep[0].data_ptr()), ctypes.c_void_p(keep[1].data_ptr()),
+                                                     ctypes.c_void_p(keep[2].data_ptr()), self._stream()))
+
+    def export_lane(self, k=0):
+        """Host snapshot of ONE env for an external viewer -- the data MujocoEnv.render / RandomCartPoleEnv.render
+        read from the sim (jinja_mujoco_env.py:175-226, random_cartpole.py:231-283): numpy qpos, qvel, xi (+ names).
+        Rendering itself stays off the GPU path."""
+        fp = ctypes.POINTER(ctypes.c_float)
+        q = np.zeros(self.dims.nq, dtype=np.float32); v = np.zeros(self.dims.nv, dtype=np.float32)
+        xi = np.zeros(self.task_dim, dtype=np.float32)
+        _native.check(self._L.rex_export_lane(self._h, int(k), q.ctypes.data_as(fp), v.ctypes.data_as(fp), xi.ctypes.data_as(fp)))
+        return dict(env_id=self.env_id, kind=self.kind, lane=int(k), qpos=q, qvel=v, task=xi,
+                    task_names=list(self.dyn_ind_to_name.values()) if hasattr(self.dyn_ind_to_name, "values") else list(self.dyn_ind_to_name))
 
     # ---- state (de)serialisation helpers used by offline-replay callers (DROPO-style), SURVEY section 8 f2 ----
     def get_sim_state(self):                  # random_hopper.py:151-152 (MjSimState -> (qpos, qvel) tensors)
@@ -230,8 +292,6 @@ class VecRandomEnv(DRConfig):
     def reset(self, mask=None):
         m = self._mask_ptr(mask)
         _native.check(self._L.rex_reset(self._h, m, ctypes.c_void_p(self._obs.data_ptr()), self._stream()))
-        if mask is not None:   # lanes not reset still need a valid observation
-            pass
         return self._obs.t()
 
     def step(self, action):
@@ -248,6 +308,8 @@ class VecRandomEnv(DRConfig):
             ctypes.c_void_p(self._reward.data_ptr()), ctypes.c_void_p(self._done.data_ptr()),
             ctypes.c_void_p(self._trunc.data_ptr()), ctypes.c_void_p(self._term_obs.data_ptr()), self._stream()))
         info = {"TimeLimit.truncated": self._trunc.bool(), "terminal_observation": self._term_obs.t()}
+        for k, name in enumerate(self.INFO_TERMS[self.kind]):    # per-term rewards, [batch] each
+            info[name] = self._info[k]
         return self._obs.t(), self._reward, self._done.bool(), info
 
     def step_soa(self, action_soa):

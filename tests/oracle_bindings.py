@@ -110,6 +110,36 @@ def oracle_humanoid_step(qpos, qvel, action, xi, xipos_x_prev=None, nthreads=8):
     return dict(qpos=qo.T.copy(), qvel=vo.T.copy(), obs=obs.T.copy(), reward=r, done=dn.astype(bool), xipos_x=xo.T.copy())
 
 
+def oracle_humanoid_reset_obs(qpos, qvel, xi):
+    """Observation of reset() / set_state at (qpos[n,24], qvel[n,23]) with the task xi[n,30] in force
+    (random_humanoid.py:219-234): (obs[n,376], xipos_x[n,14])."""
+    L = lib()
+    q, v, x = _soa(qpos, 24), _soa(qvel, 23), _soa(xi, 30)
+    n = q.shape[1]
+    obs = np.zeros((376, n)); xo = np.zeros((14, n))
+    rc = L.mjo_humanoid_batch_reset_obs(n, _p(q), _p(v), _p(x), _p(obs), _p(xo))
+    assert rc == 0
+    return obs.T.copy(), xo.T.copy()
+
+
+def oracle_sensitivity(step_fn, inputs, keys, rel=2.0 ** -22, trials=3, seed=0):
+    """How far the ORACLE's own outputs move when its inputs move by fp32-rounding-sized amounts: per lane, the largest
+    |out(x + dx) - out(x)| over `trials` random perturbations dx ~ +-rel * (1 + |x|) of every input array.
+    A lane whose GPU-vs-oracle error exceeds the stated tolerance is `explained` only if the oracle itself is that
+    ill-conditioned there (a contact / limit / solver active-set switch within rounding of the inputs)."""
+    rng = np.random.RandomState(seed)
+    base = step_fn(*inputs)
+    sens = {k: np.zeros(np.asarray(base[k]).shape[0]) for k in keys}
+    for _ in range(trials):
+        pert = [x + rel * (1 + np.abs(x)) * rng.choice([-1.0, 1.0], size=x.shape) for x in inputs]
+        out = step_fn(*pert)
+        for k in keys:
+            d = np.abs(np.asarray(out[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64))
+            d = d.reshape(d.shape[0], -1).max(1)
+            sens[k] = np.maximum(sens[k], np.where(np.isfinite(d), d, np.inf))
+    return base, sens
+
+
 def oracle_constants(kind, size=None):
     L = lib()
     bm = np.zeros(16); bi = np.zeros(16 * 9); ip = np.zeros(16 * 3); iw = np.zeros(32); dw = np.zeros(24); q0 = np.zeros(26)

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], cwd=ROOT, capture_output=True, text=True, timeout=600)
+def _run(*extra, launcher=()):
+    out = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *extra], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -41,3 +41,37 @@ def test_humanoid_line():
     assert "RandomHumanoid-v0" in d["config"]["workload"] and d["value"] > 1e5
     assert d["roofline"]["bytes_per_env_step"] == 2073 and d["roofline"]["kernel"] == "humanoid_step_kernel"
     assert d["nonfinite_lanes"] == 0
+
+
+def test_driver_command_reports_the_steady_state():
+    """`bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command) against a 400-step run: no one-time cost inside the
+    timed region (round 1 paid ~80 ms of first-use event set-up there: 4.1 ms per step instead of 0.14)."""
+    short = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    long_ = _run("--gpus", "1", "--steps", "400", "--warmup", "50", "--no-cpu-baseline")
+    assert short["config"]["global_batch"] == 32768
+    assert abs(short["value"] - long_["value"]) < 0.10 * long_["value"], (short["value"], long_["value"])
+    for d in (short, long_):
+        r = d["roofline"]
+        # the line is self-consistent: wall-clock fraction next to the kernel-time one, and the gap between them
+        assert abs(r["frac_wall"] - d["value"] * r["bytes_per_env_step"] / 1e9 / r["peak"]) < 1e-9
+        assert r["frac_wall"] <= r["frac"] * 1.02
+        assert d["host_gap_ms"] is not None and d["host_gap_ms"] < 0.25 * d["ms_per_step"] * d["steps"]
+
+
+def test_two_rank_rehearsal_on_one_gpu():
+    """The N > 1 launch path of bench.py end to end (one process per rank through torch.distributed.run, gloo, both ranks
+    on GPU 0): SUM of the asynchronous step counter, MAX of the time, strong and weak sharding, and shard independence of the
+    results -- RCCL itself needs the driver's multi-GPU node."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    launcher = ("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port))
+    common = ("--gpus", "2", "--steps", "24", "--warmup", "4", "--backend", "gloo", "--same-device", "--no-cpu-baseline",
+              "--counter-every", "8")
+    weak = _run(*common, "--batch", "4096", launcher=launcher)
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["global_batch"] == 8192
+    assert abs(weak["value"] - 8192 * 24 / (weak["ms_per_step"] * 24 / 1e3)) < 1e-6 * weak["value"]
+    assert weak["counter_reductions"] == 4                                 # 3 in-loop + the final drain
+    strong = _run(*common, "--batch", "4096", "--scaling", "strong", launcher=launcher)
+    assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 4096
+    assert "batch 2048 per GPU" in strong["config"]["workload"]

@@ -23,27 +23,46 @@ def _states(n, seed):
     return [x.astype(np.float32).astype(np.float64) for x in (q, v, a, xi)]
 
 
-def test_step_parity_and_second_step(torch_mod):
+# per-lane gates (parity_util): stated fp32 tolerance for the humanoid (PGS capped at 50 sweeps amplifies rounding), cap
+TOL_OBS, CAP_OBS = 2e-4, 2e-2
+TOL_QVEL, CAP_QVEL = 5e-4, 5e-2
+TOL_REW, CAP_REW = 2e-3, 2e-1
+
+
+@pytest.mark.parametrize("lanes", [None, 64])
+def test_step_parity_and_second_step(torch_mod, lanes):
+    """Every lane within tolerance or explained by the oracle's own conditioning; default launch shape and 64-lane blocks
+    (the > 64 KB dynamic-LDS configuration rex uses from 65 536 envs up)."""
     import random_envs_amd as rex
-    from oracle_bindings import oracle_humanoid_step
+    from oracle_bindings import oracle_humanoid_step, oracle_sensitivity
+    from parity_util import assert_done_explained, assert_lanes_explained, lanes_per_block
     torch = torch_mod
     n = 1024
     q, v, a, xi = _states(n, 3)
-    env = rex.make("RandomHumanoid-v0", batch=n, autoreset=False)
+    with lanes_per_block(lanes):
+        env = rex.make("RandomHumanoid-v0", batch=n, autoreset=False)
     assert env.task_dim == 30 and env.dims.obs_dim == 376 and env.dims.act_dim == 17
     env.set_task(xi.astype(np.float32)); env.set_state(q, v)
     obs, r, d, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
-    ref = oracle_humanoid_step(q, v, a, xi)
+    ref, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_humanoid_step(q_, v_, a_, x_), [q, v, a, xi],
+                                   ["obs", "qvel", "reward"], trials=2)
     o = obs.cpu().numpy().astype(np.float64)
-    eo = np.abs(o - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    os_ = 1 + np.abs(ref["obs"]).max(1)
+    eo = np.abs(o - ref["obs"]).max(1) / os_
     qq, vv = env.get_state()
-    ev = np.abs(vv.cpu().numpy() - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    vs = 1 + np.abs(ref["qvel"]).max(1)
+    ev = np.abs(vv.cpu().numpy() - ref["qvel"]).max(1) / vs
     # stated fp32 tolerance for the humanoid (PGS capped at 50 sweeps amplifies rounding): p99 < 5e-4, median < 2e-5
     assert np.percentile(ev, 99) < 5e-4 and np.median(ev) < 2e-5, (np.percentile(ev, 99), ev.max())
     assert np.percentile(eo, 99) < 2e-4, (np.percentile(eo, 99), eo.max())
+    tag = "humanoid lanes=%s" % lanes
+    assert_lanes_explained(eo, sens["obs"] / os_, TOL_OBS, CAP_OBS, label=tag + " |dobs|rel")
+    assert_lanes_explained(ev, sens["qvel"] / vs, TOL_QVEL, CAP_QVEL, label=tag + " |dqvel|rel")
     er = np.abs(r.cpu().numpy() - ref["reward"])
     assert np.percentile(er, 99) < 2e-3
-    assert (d.cpu().numpy() != ref["done"]).mean() < 0.005
+    assert_lanes_explained(er, sens["reward"], TOL_REW, CAP_REW, label=tag + " |dreward|")
+    z = ref["qpos"][:, 2]
+    assert_done_explained(d.cpu().numpy(), ref["done"], np.minimum(np.abs(z - 1.0), np.abs(z - 2.0)), 2e-5, label=tag)
     assert np.all(o[:, 292:] == 0)                                   # cfrc_ext block (SURVEY Q15)
     # second step: mass_center() "before" comes from the xipos the previous step left behind
     a2 = np.random.RandomState(9).uniform(-.4, .4, (n, 17)).astype(np.float32).astype(np.float64)
@@ -52,7 +71,56 @@ def test_step_parity_and_second_step(torch_mod):
     ref2 = oracle_humanoid_step(q1, v1, a2, xi, xipos_x_prev=ref["xipos_x"])
     er2 = np.abs(r2.cpu().numpy() - ref2["reward"])
     assert np.percentile(er2, 99) < 5e-3, np.percentile(er2, 99)
-    c = env.counters(); assert c["nonfinite"] == 0
+    c = env.counters(); assert c["nonfinite"] == 0 and c["overflow"] == 0
+    env.close()
+
+
+@pytest.mark.parametrize("lanes", [None, 64])
+def test_reset_and_set_state_observation_vs_oracle(torch_mod, lanes):
+    """a9 / SURVEY Q10: reset_model = set_state (sim.forward() with the masses in force, i.e. the PREVIOUS episode's)
+    -> set_random_task -> _get_obs (random_humanoid.py:219-234).  humanoid_reset_kernel and humanoid_forward_kernel
+    against oracle/mjo_humanoid.c::mjo_humanoid_batch_reset_obs, the cinert block with the OLD masses."""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_humanoid_reset_obs
+    from parity_util import lanes_per_block
+    torch = torch_mod
+    n = 2048
+    with lanes_per_block(lanes):
+        env = rex.make("RandomHumanoid-v0", batch=n, seed=21, autoreset=False)
+    lo, hi = env.get_task_search_bounds()
+    env.set_dr_distribution("uniform", np.stack([lo, hi], 1).ravel().tolist()); env.set_dr_training(True)
+    env.reset()                                                       # episode 1: xi_1 drawn
+    xi_old = env.get_task().cpu().numpy().astype(np.float64)
+    obs = env.reset().cpu().numpy().astype(np.float64)                # episode 2: obs built with xi_1, THEN xi_2 drawn
+    xi_new = env.get_task().cpu().numpy().astype(np.float64)
+    assert np.abs(xi_new - xi_old).max() > 0.1
+    q, v = env.get_state()
+    q = q.cpu().numpy().astype(np.float64); v = v.cpu().numpy().astype(np.float64)
+    ref_old, _ = oracle_humanoid_reset_obs(q, v, xi_old)
+    ref_new, _ = oracle_humanoid_reset_obs(q, v, xi_new)
+    sc = 1 + np.abs(ref_old).max(1)
+    e_old = np.abs(obs - ref_old).max(1) / sc
+    e_new = np.abs(obs - ref_new).max(1) / sc
+    print("reset obs vs oracle(old masses): max %.2e | vs oracle(new masses): median %.2e" % (e_old.max(), np.median(e_new)))
+    assert e_old.max() < 2e-5, e_old.max()                            # one forward, no solver: every lane, tight
+    assert np.median(e_new) > 1e-2                                    # ... and it is NOT the new masses' observation
+    assert np.array_equal(obs[:, :22], q[:, 2:].astype(np.float32).astype(np.float64))
+    # set_state -> sim.forward() -> _get_obs with the CURRENT task (humanoid_forward_kernel via rex_get_obs)
+    rng = np.random.RandomState(4)
+    q2 = q.copy(); q2[:, 7:] += rng.uniform(-.4, .4, (n, 17)); v2 = rng.uniform(-2, 2, (n, 23))
+    q2, v2 = q2.astype(np.float32).astype(np.float64), v2.astype(np.float32).astype(np.float64)
+    env.set_state(q2, v2)
+    o2 = torch.empty(376, n, device="cuda")
+    import ctypes
+    from random_envs_amd import _native
+    _native.check(_native.lib().rex_get_obs(env._h, ctypes.c_void_p(o2.data_ptr()), env._stream()))
+    o2 = o2.t().cpu().numpy().astype(np.float64)
+    ref2, xip = oracle_humanoid_reset_obs(q2, v2, xi_new)
+    e2 = np.abs(o2 - ref2).max(1) / (1 + np.abs(ref2).max(1))
+    assert e2.max() < 2e-5, e2.max()
+    # the xipos that forward left behind is what the next step's mass_center() "before" reads
+    st = env.get_full_state()
+    assert np.abs(st["aux"].t().cpu().numpy() - xip).max() < 1e-5
     env.close()
 
 

@@ -1,5 +1,5 @@
 """N > 1 launch path on CPU: world_size 2, gloo.  Covers the sharding arithmetic and the only
-collectives the path uses (SUM of the step counter, MAX of the elapsed time)."""
+collectives the path uses (SUM of the step counter -- issued asynchronously every K steps -- and MAX of the elapsed time)."""
 import os
 import socket
 import subprocess
@@ -19,8 +19,17 @@ assert (off, b) == (rank * 32768, 32768)
 so, sb = sharding.shard_strong(32769, rank, world)
 steps = 10 * b + rank                      # each rank "did" a different amount of work
 total, tmax = sharding.reduce_counter_and_time(steps, 1.0 + rank, torch.device("cpu"))
+# the asynchronous counter of bench.py: 25 batched steps, an all-reduce in flight every 8 of them
+ctr = sharding.StepCounter(torch.device("cpu"), every=8)
+lag = []
+for k in range(25):
+    ctr.add(b + rank)
+    lag.append(ctr.last_global)
+atotal = ctr.total()
+tmax2 = sharding.reduce_max(1.0 + rank, torch.device("cpu"))
 sharding.barrier()
-print(json.dumps(dict(rank=rank, off=off, so=so, sb=sb, total=total, tmax=tmax)), flush=True)
+print(json.dumps(dict(rank=rank, off=off, so=so, sb=sb, total=total, tmax=tmax, atotal=atotal, nred=ctr.reductions,
+                      lag=lag[-1], tmax2=tmax2)), flush=True)
 sharding.shutdown()
 """
 
@@ -48,7 +57,11 @@ def test_two_rank_gloo_sharding_and_counter(tmp_path):
     outs.sort(key=lambda d: d["rank"])
     assert [d["off"] for d in outs] == [0, 32768]
     assert all(d["total"] == 10 * 32768 * 2 + 1 for d in outs)          # SUM over ranks
-    assert all(d["tmax"] == 2.0 for d in outs)                          # MAX over ranks
+    assert all(d["tmax"] == 2.0 and d["tmax2"] == 2.0 for d in outs)    # MAX over ranks
+    # asynchronous counter: exact total after the drain, 3 in-loop reductions + the final one; the running value the
+    # ranks see lags (the reduction issued at step 16 is the newest one waited for inside the loop)
+    assert all(d["atotal"] == 25 * (2 * 32768 + 1) and d["nred"] == 4 for d in outs)
+    assert all(d["lag"] == 16 * (2 * 32768 + 1) for d in outs)
     # strong split covers the global batch exactly once
     assert outs[0]["so"] == 0 and outs[1]["so"] == outs[0]["sb"] and outs[0]["sb"] + outs[1]["sb"] == 32769
 
