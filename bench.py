@@ -135,7 +135,7 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if rank == 0:
+    if rank == 0 and not os.environ.get("REX_LIB"):   # REX_LIB: a tuning build chosen by hand (profiles/ab_bench.sh)
         graft.build()
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live

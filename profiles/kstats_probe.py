@@ -16,5 +16,5 @@ for eid in (sys.argv[1:] or ["RandomHopper-v0"]):
     for k in range(200): env.step_soa(acts[k%8])
     torch.cuda.synchronize()
     _native.lib().rex_debug_kstats(out); o=list(out)
-    print(eid,'wave-solves',o[0],'pass1/solve %.2f pass2/solve %.2f ls_evals/solve %.2f nocon %.3f union-slots/solve %.2f'%(o[2]/o[0],o[3]/o[0],o[4]/o[0],o[5]/o[0],o[6]/o[0]))
+    print(eid,'wave-solves',o[0],'pass1/solve %.2f pass2/solve %.2f ls_evals/solve %.2f nocon %.3f union-slots/solve %.2f fast-path %.3f'%(o[2]/o[0],o[3]/o[0],o[4]/o[0],o[5]/o[0],o[6]/o[0],o[7]/o[0]))
     env.close()

@@ -1,7 +1,7 @@
 """Diagnostic: distribution over the waves of one launch of the cycles spent in the substeps (build with -DREX_WAVETIME).
 At B = 32 768 every wave has its own SIMD, so the kernel time is the slowest wave's."""
 import os, sys, ctypes
-os.environ["REX_LIB"] = "librex_hip_wavetime.so"
+os.environ.setdefault("REX_LIB", "librex_hip_wavetime.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, random_envs_amd as rex
 from random_envs_amd import _native
@@ -22,6 +22,13 @@ for eid in sys.argv[1:] or ["RandomHopper-v0"]:
         _native.lib().rex_debug_waveinfo(info, 1024)
         rows.append(np.array(list(out), dtype=np.float64)); infos.append(np.array(list(info), dtype=np.float64).reshape(1024, 8))
     w = np.stack(rows); I = np.stack(infos)
+    if hasattr(_native.lib(), "rex_debug_wavephase") and "Humanoid" not in eid:
+        ph = (ctypes.c_ulonglong * (1024 * 4))(); _native.lib().rex_debug_wavephase(ph, 1024)
+        P = np.array(list(ph), dtype=np.float64).reshape(1024, 4)
+        env.enable_timing(True); env.step_soa(acts[0]); torch.cuda.synchronize(); ms = env.read_timing()[-1]; env.enable_timing(False)
+        print("   last launch, cycles per wave [mean / max]: load state %.0f / %.0f | substeps %.0f / %.0f | reward, obs, stores %.0f / %.0f | fused reset %.0f / %.0f | "
+              "sum of means %.0f, slowest wave %.0f; kernel %.4f ms" % (P[:, 0].mean(), P[:, 0].max(), P[:, 1].mean(), P[:, 1].max(), P[:, 2].mean(), P[:, 2].max(),
+                                                                     P[:, 3].mean(), P[:, 3].max(), P.sum(1).mean(), P.sum(1).max(), ms))
     print(eid, "cycles per wave-step: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f  -> max/mean %.2f" %
           (w.mean(), np.percentile(w, 50), np.percentile(w, 90), np.percentile(w, 99), w.max(1).mean(), w.max(1).mean() / w.mean()))
     print("   cycles in the fused reset path per wave-step: mean %.0f  p90 %.0f  max %.0f" % (I[..., 1].mean(), np.percentile(I[..., 1], 90), I[..., 1].max(1).mean()))

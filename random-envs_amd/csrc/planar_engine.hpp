@@ -198,6 +198,7 @@ template <class T, class S>
 struct Constraints {
   static constexpr int NC = 2 * S::NG;
   T px[NC], pz[NC];      // contact point relative to the root anchor
+  T dist[NC];            // signed distance of the capsule end to the floor
   T D[NC];               // 1/R of the pyramid edges
   T an[NC], at[NC];      // reference accelerations: edges are (an +/- at) and an (twice)
   unsigned con_mask;     // bit k: slot k within margin
@@ -279,6 +280,45 @@ REX_HD void hess_accum(const Kin<T, S>& K, T px, T pz, T ctt, T cnt, T cnn, T (&
   });
 }
 
+// The same four operations with the hinge columns of the point Jacobian given (jt[j], jn[j] = tangential / normal entry of
+// dof j + 2, ancestors of body B only): the straight-line solver instantiation forms them once per evaluation instead of
+// re-deriving the lever arms at every use.
+template <class T, class S, int B>
+REX_HD void point_jac(const Kin<T, S>& K, T px, T pz, T (&jt)[S::NB], T (&jn)[S::NB]) {
+  static_for<0, S::NB>([&](auto JJ) {
+    constexpr int j = JJ;
+    if constexpr (is_anc_or_self<S>(j, B)) { constexpr T sj = T(S::sgn[j]); jt[j] = sj * (pz - K.A[j][1]); jn[j] = -sj * (px - K.A[j][0]); }
+  });
+}
+template <class T, class S, int B>
+REX_HD void jdot_pre(const T (&jt)[S::NB], const T (&jn)[S::NB], const T (&x)[S::NV], T& t, T& n) {
+  t = x[0]; n = x[1];
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; if constexpr (is_anc_or_self<S>(j, B)) { t += jt[j] * x[j + 2]; n += jn[j] * x[j + 2]; } });
+}
+template <class T, class S, int B>
+REX_HD void jt_accum_pre(const T (&jt)[S::NB], const T (&jn)[S::NB], T ft, T fn, T (&g)[S::NV]) {
+  g[0] += ft; g[1] += fn;
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; if constexpr (is_anc_or_self<S>(j, B)) g[j + 2] += jt[j] * ft + jn[j] * fn; });
+}
+template <class T, class S, int B>
+REX_HD void hess_accum_pre(const T (&jt)[S::NB], const T (&jn)[S::NB], T ctt, T cnt, T cnn, T (&H)[S::NV][S::NV]) {
+  T ut[S::NV], un[S::NV], wt[S::NV], wn[S::NV];
+  ut[0] = T(1); un[0] = T(0); ut[1] = T(0); un[1] = T(1);
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; if constexpr (is_anc_or_self<S>(j, B)) { ut[j + 2] = jt[j]; un[j + 2] = jn[j]; } });
+  static_for<0, S::NV>([&](auto AA) {
+    constexpr int a = AA;
+    if constexpr (a < 2 || is_anc_or_self<S>(a - 2, B)) { wt[a] = ctt * ut[a] + cnt * un[a]; wn[a] = cnt * ut[a] + cnn * un[a]; }
+  });
+  static_for<0, S::NV>([&](auto AA) {
+    constexpr int a = AA;
+    if constexpr (a < 2 || is_anc_or_self<S>(a - 2, B))
+      static_for<0, a + 1>([&](auto BB) {
+        constexpr int b = BB;
+        if constexpr (b < 2 || is_anc_or_self<S>(b - 2, B)) H[a][b] += wt[a] * ut[b] + wn[a] * un[b];
+      });
+  });
+}
+
 // capsule centre / half-axis of geom g in world axes (relative to the root anchor)
 template <class T, class S, int g>
 REX_HD void capsule_pose(const Kin<T, S>& K, const PlanarGeom<T, S>& G, T (&p)[2], T (&a)[2], T& l) {
@@ -337,12 +377,24 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
   });
 }
 
+// f(IC<k>) for every slot k of the compile-time set SLOTS (bit k), in increasing order
+template <unsigned SLOTS, class F>
+REX_HD void for_slots(F&& f) {
+  static_for<0, 32>([&](auto KK) { constexpr int k = KK; if constexpr ((SLOTS >> k) & 1u) f(IC<k>{}); });
+}
+template <class S> constexpr unsigned all_slots() { return (2 * S::NG >= 32) ? ~0u : ((1u << (2 * S::NG)) - 1u); }
+
 // collision + constraint rows + reference accelerations  ([3P] mj_collision, mj_makeConstraint,
-// mj_diagApprox, mj_makeImpedance, mj_referenceConstraint)
+// mj_diagApprox, mj_makeImpedance, mj_referenceConstraint), in two parts:
+//   detect_constraints  joint-limit rows, the distance of every capsule end to the floor (which slots are inside the
+//                       margin), the bounding-circle cull of the self pairs -- cheap, branch-free, decides which solver
+//                       instantiation the wave enters;
+//   slot_rows<SLOTS>    impedance, regularisation and reference acceleration of the floor slots in SLOTS; with BR the
+//                       slots no lane of the wave touches are skipped by a wave-uniform branch, without BR the code is
+//                       straight-line (the fast path: a handful of slots, one basic block).
 template <class T, class S>
-REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const PlanarGeom<T, S>& G,
-                             const LaneParams<T, S>& P, const SolParams<T>& sp, const Kin<T, S>& K,
-                             Constraints<T, S>& C) {
+REX_HD void detect_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const PlanarGeom<T, S>& G,
+                               const SolParams<T>& sp, const Kin<T, S>& K, Constraints<T, S>& C) {
   unsigned lim_mask = 0, con_mask = 0;
   // joint limits (hinge bodies 1..NB-1)
   static_for<1, S::NB>([&](auto JJ) {
@@ -370,18 +422,9 @@ REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const Pla
       T ox, oz; rot(K.c[b], K.s[b], lx, lz, ox, oz);
       T cx = K.A[b][0] + ox, cz = K.A[b][1] + oz;     // sphere centre rel. root anchor
       T dist = (cz + K.zroot) - G.radius[g];
-      bool act = dist < sp.con_margin;
-      if (act) con_mask |= 1u << k;
+      if (dist < sp.con_margin) con_mask |= 1u << k;
       C.px[k] = cx; C.pz[k] = T(0.5) * dist - K.zroot;   // midpoint between the surfaces
-      if (REX_WAVE_ANY(act)) {
-        T mu = P.mu[g], mu2 = mu * mu;
-        T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist - sp.con_margin));
-        // R1 = (1-imp)/imp * tran*(1+mu^2) ; Rpy = 2 mu^2 R1 ; D = 1/Rpy
-        C.D[k] = imp * rcp_t(max_t(T(1e-15), T(2) * mu2 * (T(1) - imp) * (G.tran_invw[b] * (T(1) + mu2))));
-        T vt, vn; jdot<T, S, b>(K, C.px[k], C.pz[k], v, vt, vn);
-        C.an[k] = -sp.con_B * vn - sp.con_K * imp * (dist - sp.con_margin);
-        C.at[k] = -sp.con_B * mu * vt;
-      } else { C.D[k] = T(0); C.an[k] = T(0); C.at[k] = T(0); }
+      C.dist[k] = dist;
     });
   });
   C.lim_mask = lim_mask; C.con_mask = con_mask;
@@ -403,6 +446,27 @@ REX_HD void make_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const Pla
   }
   C.self_possible = sp_any;
   C.any = (lim_mask | con_mask) != 0u;
+}
+
+template <class T, class S, unsigned SLOTS, bool BR>
+REX_HD void slot_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const LaneParams<T, S>& P, const SolParams<T>& sp,
+                      const Kin<T, S>& K, Constraints<T, S>& C) {
+  for_slots<SLOTS>([&](auto KK) {
+    constexpr int k = KK; constexpr int g = k / 2; constexpr int b = S::geom_body[g];
+    const bool act = (C.con_mask >> k) & 1u;
+    bool go = true;
+    if constexpr (BR) go = REX_WAVE_ANY(act);
+    if (go) {
+      const T dist = C.dist[k];
+      T mu = P.mu[g], mu2 = mu * mu;
+      T imp = impedance(sp.con_dmin, sp.con_dmax, sp.con_width, abs_t(dist - sp.con_margin));
+      // R1 = (1-imp)/imp * tran*(1+mu^2) ; Rpy = 2 mu^2 R1 ; D = 1/Rpy
+      C.D[k] = imp * rcp_t(max_t(T(1e-15), T(2) * mu2 * (T(1) - imp) * (G.tran_invw[b] * (T(1) + mu2))));
+      T vt, vn; jdot<T, S, b>(K, C.px[k], C.pz[k], v, vt, vn);
+      C.an[k] = -sp.con_B * vn - sp.con_K * imp * (dist - sp.con_margin);
+      C.at[k] = -sp.con_B * mu * vt;
+    } else { C.D[k] = T(0); C.an[k] = T(0); C.at[k] = T(0); }
+  });
 }
 
 template <class T, class S>
@@ -439,7 +503,14 @@ REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const
   R.mask = mask;
 }
 
-struct SolveStats { int iters; bool capped; };
+// -DREX_MARKS: comment markers in the ISA (profiles/isa_regions.py counts the instructions between them)
+#if defined(REX_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define REX_MARK(name) asm volatile("; REXMARK " name)
+#else
+#define REX_MARK(name) ((void)0)
+#endif
+
+struct SolveStats { int iters; bool capped; int mode; };   // mode: solver instantiation forward() entered (0 none, 1 general, 2 general + self rows, 3 feet-only straight-line)
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; };
 inline GlobalStats& gstats() { static GlobalStats g{}; return g; }
@@ -464,16 +535,23 @@ enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4,
 // All lanes of a wave iterate together; a lane that has converged keeps alpha = 0.  Rows are
 // re-derived from (contact point, anchors) on the fly and slots no lane of the wave touches are
 // skipped with a wave-uniform branch: the solver's live state is M, H, g and 5 floats per slot.
-template <class T, class S, bool SELF, int MAXIT = 24>
+// SLOTS: compile-time set of floor slots this instantiation looks at; BR: skip the slots no lane of the wave touches with
+// a wave-uniform branch (general path) or run them all straight-line (fast path: few slots, no branches in an iteration).
+template <bool BR> REX_HD bool any_lane(bool x) { if constexpr (BR) return REX_WAVE_ANY(x); else return true; }
+template <class T, class S, bool SELF, unsigned SLOTS, bool BR, int MAXIT = 24>
 REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
                                const Kin<T, S>& K, const Constraints<T, S>& C, const SelfRows<T, S>& R,
-                               const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, int ls_max) {
+                               const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, bool have_a0, int ls_max) {
   // MuJoCo starts at qacc_smooth (warmstart is disabled in all the XMLs); the minimiser is unique, so
   // starting from the previous RK4 stage's solution only changes how fast the active set is found
   // (a lane without any row is only here because another lane of its wave has one: it must leave with qacc_smooth)
+  // With a warm start qacc_smooth is NOT computed (forward() skips that factorisation): a lane without rows then takes one
+  // Newton step like everybody else -- its Hessian is M itself, so the step lands on M^-1 qfrc_smooth exactly.
+  // (have_a0: qacc_smooth was computed -- cold starts, and every solve when the `fast` knob is off: then a lane without rows
+  // leaves with qacc_smooth itself and its arithmetic does not depend on what the other lanes of its wave are doing.)
   const bool has_rows = C.any || (SELF && R.mask != 0u);
-  static_for<0, S::NV>([&](auto II) { qacc[II] = (warm && has_rows) ? qacc[II] : qacc_smooth[II]; });
-  SolveStats st{0, false};
+  static_for<0, S::NV>([&](auto II) { qacc[II] = have_a0 ? ((warm && has_rows) ? qacc[II] : qacc_smooth[II]) : qacc[II]; });
+  SolveStats st{0, false, 0};
   // stop when the force residual |M a - f - J^T f_c| is at rounding level relative to the forces
   // that balance in it (the piecewise-quadratic cost makes Newton exact once the active set is right)
   const T tol2 = sizeof(T) == 4 ? T(1e-9) : T(1e-24);
@@ -482,13 +560,17 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
   // every row kept its sign along the step (rows are linear in alpha), the cost was exactly
   // quadratic there and the step was its exact minimiser -> converged, independent of rounding
   unsigned p_lim = ~0u, p_e1 = ~0u, p_e2 = ~0u, p_e3 = ~0u, p_self = ~0u;
-  bool lane_done = !has_rows;
+  bool lane_done = !has_rows && have_a0;
   constexpr int NC = 2 * S::NG;
+  // straight-line instantiation: hinge columns of the point Jacobians once per solve; J qacc of pass 1 is reused by pass 2
+  T Jt[BR ? 1 : NC][S::NB], Jn[BR ? 1 : NC][S::NB], lt[NC], ln[NC];
+  if constexpr (!BR) for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; point_jac<T, S, S::geom_body[k / 2]>(K, C.px[k], C.pz[k], Jt[k], Jn[k]); });
   for (int it = 0; it < MAXIT; ++it) {
     if (!REX_WAVE_ANY(!lane_done)) break;
     T cpx[NC], cpz[NC];   // per-iteration opaque copies of the contact points (see opaque())
-    static_for<0, NC>([&](auto KK) { constexpr int k = KK; cpx[k] = C.px[k]; cpz[k] = C.pz[k]; opaque(cpx[k]); opaque(cpz[k]); });
+    if constexpr (BR) for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; cpx[k] = C.px[k]; cpz[k] = C.pz[k]; opaque(cpx[k]); opaque(cpz[k]); });
     REX_COUNT(pass1, 1);
+    REX_MARK("pass1");
     // ---- pass 1: gradient and active edges --------------------------------------------------
     T g[S::NV], Ma[S::NV];
     sym_matvec<T, S>(M, qacc, Ma);
@@ -504,21 +586,23 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
         g[j + 2] += on ? C.lsig[j] * C.lD[j] * jar : T(0);
       }
     });
-    static_for<0, S::NG>([&](auto GG) {
-      constexpr int gg = GG; constexpr int b = S::geom_body[gg];
-      static_for<0, 2>([&](auto EE) {
-        constexpr int k = 2 * gg + EE;
+    for_slots<SLOTS>([&](auto KK) {
+      {
+        constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
         const bool act = (C.con_mask >> k) & 1u;
-        if (REX_WAVE_ANY(act)) {
+        if (any_lane<BR>(act)) {
           const T mu = P.mu[gg];
-          T jt, jn; jdot<T, S, b>(K, cpx[k], cpz[k], qacc, jt, jn);
+          T jt, jn;
+          if constexpr (BR) jdot<T, S, b>(K, cpx[k], cpz[k], qacc, jt, jn);
+          else { jdot_pre<T, S, b>(Jt[k], Jn[k], qacc, jt, jn); lt[k] = jt; ln[k] = jn; }
           T r1 = jn + mu * jt - (C.an[k] + C.at[k]), r2 = jn - mu * jt - (C.an[k] - C.at[k]), r3 = jn - C.an[k];
           bool s1 = act && r1 < T(0), s2 = act && r2 < T(0), s3 = act && r3 < T(0);
           if (s1) e1 |= 1u << k; if (s2) e2 |= 1u << k; if (s3) e3 |= 1u << k;
           T f1 = s1 ? -C.D[k] * r1 : T(0), f2 = s2 ? -C.D[k] * r2 : T(0), f3 = s3 ? -C.D[k] * r3 : T(0);
-          jt_accum<T, S, b>(K, cpx[k], cpz[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
+          if constexpr (BR) jt_accum<T, S, b>(K, cpx[k], cpz[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
+          else jt_accum_pre<T, S, b>(Jt[k], Jn[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
         }
-      });
+      }
     });
     if constexpr (SELF && S::NSELF > 0) {
       static_for<0, 2 * S::NSELF>([&](auto PP) {
@@ -545,23 +629,24 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     lane_done = lane_done || same_set || !(gn > tol2 * fref);   // NaN counts as done
     if (!REX_WAVE_ANY(!lane_done)) break;
     REX_COUNT(pass2, 1);
+    REX_MARK("pass2_hess");
     // ---- pass 2: Hessian of the current active set, Newton direction ------------------------
     T H[S::NV][S::NV];
     static_for<0, S::NV>([&](auto II) { constexpr int i = II;
       static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] = M[i][j]; }); });
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
       if constexpr (S::limited[j]) H[j + 2][j + 2] += ((lim_on >> j) & 1u) ? C.lD[j] : T(0); });
-    static_for<0, S::NG>([&](auto GG) {
-      constexpr int gg = GG; constexpr int b = S::geom_body[gg];
-      static_for<0, 2>([&](auto EE) {
-        constexpr int k = 2 * gg + EE;
+    for_slots<SLOTS>([&](auto KK) {
+      {
+        constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
         const unsigned bit = 1u << k;
-        if (REX_WAVE_ANY(((e1 | e2 | e3) & bit) != 0u)) {
+        if (any_lane<BR>(((e1 | e2 | e3) & bit) != 0u)) {
           const T mu = P.mu[gg];
           T s1 = (e1 & bit) ? T(1) : T(0), s2 = (e2 & bit) ? T(1) : T(0), s3 = (e3 & bit) ? T(1) : T(0);
-          hess_accum<T, S, b>(K, cpx[k], cpz[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), H);
+          if constexpr (BR) hess_accum<T, S, b>(K, cpx[k], cpz[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), H);
+          else hess_accum_pre<T, S, b>(Jt[k], Jn[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), H);
         }
-      });
+      }
     });
     if constexpr (SELF && S::NSELF > 0) {
       static_for<0, 2 * S::NSELF>([&](auto PP) {
@@ -577,10 +662,12 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
         }
       });
     }
+    REX_MARK("pass2_ldl");
     ldl_factor<T, S>(H);
     T sr[S::NV];
     static_for<0, S::NV>([&](auto II) { sr[II] = -g[II]; });
     ldl_solve<T, S>(H, sr);
+    REX_MARK("pass2_ls");
     // ---- exact line search on phi(alpha); phi'(0) = g.sr, Gauss curvature sr^T M sr ----------
     T Ms[S::NV];
     sym_matvec<T, S>(M, sr, Ms);
@@ -589,17 +676,17 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     unsigned m_lim, m_e1, m_e2, m_e3, m_self;   // rows active at the last evaluated alpha
     // every row is linear in alpha: x(alpha) = r + alpha v with r = J qacc - aref, v = J sr.  The slot products J qacc, J sr
     // are formed once per Newton iteration; an evaluation of phi' is then a few multiply-adds per slot.
-    T lt[NC], ln[NC], lvt[NC], lvn[NC];
-    static_for<0, S::NG>([&](auto GG) {
-      constexpr int gg = GG; constexpr int b = S::geom_body[gg];
-      static_for<0, 2>([&](auto EE) {
-        constexpr int k = 2 * gg + EE;
+    T lvt[NC], lvn[NC];
+    for_slots<SLOTS>([&](auto KK) {
+      constexpr int k = KK; constexpr int b = S::geom_body[k / 2];
+      if constexpr (BR) {
         lt[k] = ln[k] = lvt[k] = lvn[k] = T(0);
         if (REX_WAVE_ANY((C.con_mask >> k) & 1u)) jdot2<T, S, b>(K, cpx[k], cpz[k], qacc, sr, lt[k], ln[k], lvt[k], lvn[k]);
-      });
+      } else jdot_pre<T, S, b>(Jt[k], Jn[k], sr, lvt[k], lvn[k]);   // J qacc: lt / ln of pass 1
     });
     auto deriv = [&](T a, T& d1, T& d2) {
       REX_COUNT(ls_evals, 1);
+      REX_MARK("deriv");
       m_lim = m_e1 = m_e2 = m_e3 = m_self = 0u;
       d1 = q1 + a * q2; d2 = q2;
       static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
@@ -608,12 +695,11 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           T x = lr + a * lv; bool on = ((C.lim_mask >> j) & 1u) && x < T(0);
           if (on) m_lim |= 1u << j;
           T dd = on ? C.lD[j] : T(0); d1 += dd * x * lv; d2 += dd * lv * lv; } });
-      static_for<0, S::NG>([&](auto GG) {
-        constexpr int gg = GG;
-        static_for<0, 2>([&](auto EE) {
-          constexpr int k = 2 * gg + EE;
+      for_slots<SLOTS>([&](auto KK) {
+        {
+          constexpr int k = KK; constexpr int gg = k / 2;
           const bool act = (C.con_mask >> k) & 1u;
-          if (REX_WAVE_ANY(act)) {
+          if (any_lane<BR>(act)) {
             const T mu = P.mu[gg];
             const T jt = lt[k], jn = ln[k], vt = lvt[k], vn = lvn[k];
             T r0 = jn + mu * jt - (C.an[k] + C.at[k]), r1 = jn - mu * jt - (C.an[k] - C.at[k]), r2 = jn - C.an[k];
@@ -625,7 +711,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
             d1 += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2;
             d2 += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2;
           }
-        });
+        }
       });
       if constexpr (SELF && S::NSELF > 0) static_for<0, 2 * S::NSELF>([&](auto PP) {
         constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
@@ -657,6 +743,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       deriv(a, d1, d2);
       ls_done = ls_done || abs_t(d1) <= d1ref || a == prev;
     }
+    REX_MARK("pass2_update");
     // full Newton step that stays in the region its Hessian was built for: exact minimiser, no
     // verification pass needed (same argument as `same_set` above)
     const bool exact_step = a == T(1) && m_lim == lim_on && m_e1 == e1 && m_e2 == e2 && m_e3 == e3 && m_self == self_on;
@@ -689,6 +776,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
                           const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV],
                           bool warm = false) {
   REX_STAMP(t_0);
+  REX_MARK("kinematics");
   Kin<T, S> K;
   kinematics<T, S>(q, G, K);
   REX_STAMP(t_1);
@@ -704,18 +792,12 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
     });
   }
   REX_STAMP(t_2);
-  {
-    T L[S::NV][S::NV];
-    static_for<0, S::NV>([&](auto II) { constexpr int i = II; a0[i] = f[i];
-      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) L[i][j] = M[i][j]; }); });
-    ldl_factor<T, S>(L);
-    ldl_solve<T, S>(L, a0);
-  }
   REX_STAMP(t_3);
+  REX_MARK("detect");
   Constraints<T, S> C;
-  make_constraints<T, S>(q, v, G, P, sp, K, C);
+  detect_constraints<T, S>(q, v, G, sp, K, C);
   REX_STAMP(t_4);
-  SolveStats st{0, false};
+  SolveStats st{0, false, 0};
 #if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
   { unsigned um = 0; for (int k = 0; k < 2 * S::NG; k++) if (REX_WAVE_ANY((C.con_mask >> k) & 1u)) um |= 1u << k;
     REX_COUNT(solves, 1); if (!REX_WAVE_ANY(C.any)) REX_COUNT(nocon, 1); REX_COUNT(slots_active, __popc(um)); }
@@ -736,13 +818,45 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
       self_rows = REX_WAVE_ANY(R.mask != 0u);
     }
   }
-  int mode = self_rows ? 2 : (REX_WAVE_ANY(C.any) ? 1 : 0);
+  // Which solver instantiation the wave enters (wave-uniform):
+  //   0  no row in any lane                              -> qacc = qacc_smooth
+  //   3  only the feet touch (S::FAST_SLOTS), no self row -> straight-line instantiation over those slots: no per-slot branch,
+  //      a quarter of the slot state live -- the common case of an upright walker, and the launch ends with its slowest wave
+  //   1  any other floor slot                            -> general instantiation (wave-uniform skipping of untouched slots)
+  //   2  a capsule-capsule self row (hopper)             -> general instantiation + self rows
+  constexpr unsigned ALL = all_slots<S>(), FAST = S::FAST_SLOTS & ALL;
+  const bool off_fast = REX_WAVE_ANY((C.con_mask & ~FAST) != 0u) || !sp.fast;
+  int mode = self_rows ? 2 : (REX_WAVE_ANY(C.any) ? (off_fast ? 1 : 3) : 0);
 #if defined(__HIP_DEVICE_COMPILE__)
   mode = __builtin_amdgcn_readfirstlane(mode);   // wave-uniform by construction: make it a scalar branch
 #endif
-  if (mode == 2) { if constexpr (S::NSELF > 0) st = solve_newton<T, S, true>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max); }
-  else if (mode == 1) st = solve_newton<T, S, false>(M, f, a0, K, C, R, P, qacc, warm, sp.ls_max);
-  else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+  // qacc_smooth = M^-1 qfrc_smooth ([3P] mj_fwdAcceleration) is the solver's cold start and the answer when no lane of
+  // the wave has a row; a warm-started solve does not read it (solve_newton), so 15 of the 16 evaluations of a
+  // hopper / walker2d step skip this factorisation.
+  const bool have_a0 = mode == 0 || !warm || !sp.fast;
+  if (have_a0) {
+    T L[S::NV][S::NV];
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II; a0[i] = f[i];
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) L[i][j] = M[i][j]; }); });
+    ldl_factor<T, S>(L);
+    ldl_solve<T, S>(L, a0);
+  } else static_for<0, S::NV>([&](auto II) { a0[II] = T(0); });
+  REX_MARK("dispatch");
+  if (mode == 3) {
+    REX_MARK("fast_rows");
+    slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
+    st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+  } else if (mode == 2) {
+    if constexpr (S::NSELF > 0) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max); }
+  } else if (mode == 1) {
+    slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
+    st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+  } else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+#if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
+  if (mode == 3 && (threadIdx.x & 63) == 0) atomicAdd(&g_kstats[7], 1ull);   // wave-solves on the fast path
+#endif
+  REX_MARK("forward_end");
+  st.mode = mode;
   REX_STAMP(t_5);
   REX_TACC(0, t_0, t_1); REX_TACC(1, t_1, t_2); REX_TACC(2, t_2, t_3); REX_TACC(3, t_3, t_4); REX_TACC(4, t_4, t_5);
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)

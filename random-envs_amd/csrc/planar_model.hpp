@@ -211,7 +211,7 @@ REX_HD void derive_model(const T* size, PlanarGeom<T, S>& G, T (&nominal_mass)[S
   // Re-measured once the kernel time was understood to be the SLOWEST wave's (kernel ms at ls_max 0/1/2/3): hopper
   // .138/.139/.147/.151, half-cheetah .117/.129/.134/.135, walker2d .307/.323/.345/.353 -- but without any line search (0) a few
   // walker2d waves hit the iteration cap, and 1 still did (4 waves in 1 500 steps); every env keeps at least one safeguarded step.
-  sp.ls_max = S::KIND == 3 ? 2 : 1; sp.warm = S::RK4 ? 1 : 0;
+  sp.ls_max = S::KIND == 3 ? 2 : 1; sp.warm = S::RK4 ? 1 : 0; sp.fast = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -112,6 +112,7 @@ struct HopperSpec {
   static constexpr float DEFAULT_NOISE_VAR = 1e-4f;                 // random_hopper.py:28
   static constexpr float INIT_NOISE = 0.005f;                       // random_hopper.py:113-114
   static constexpr bool DR_BEFORE_STATE = false;                    // random_hopper.py:113-118
+  static constexpr unsigned FAST_SLOTS = 0xC0u;                     // both ends of the foot capsule (slot = 2 * geom + end)
 };
 
 struct Walker2dSpec {
@@ -137,6 +138,7 @@ struct Walker2dSpec {
   static constexpr float DEFAULT_NOISE_VAR = 1e-3f;                 // random_walker2d.py:30
   static constexpr float INIT_NOISE = 0.005f;                       // random_walker2d.py:148-151
   static constexpr bool DR_BEFORE_STATE = true;                     // random_walker2d.py:145-151
+  static constexpr unsigned FAST_SLOTS = (3u << 6) | (3u << 12);    // the two foot capsules (geoms 3 and 6)
 };
 
 struct HalfCheetahSpec {
@@ -162,6 +164,7 @@ struct HalfCheetahSpec {
   static constexpr float DEFAULT_NOISE_VAR = 1e-4f;                 // random_half_cheetah.py:30
   static constexpr float INIT_NOISE = 0.1f;                         // random_half_cheetah.py:124-125
   static constexpr bool DR_BEFORE_STATE = false;
+  static constexpr unsigned FAST_SLOTS = (3u << 8) | (3u << 14);    // bfoot and ffoot (geoms 4 and 7)
 };
 
 // compile-time tree helpers --------------------------------------------------------------
@@ -211,6 +214,7 @@ struct SolParams {
   T meaninertia;   // scale of the convergence test
   int ls_max;      // cap on extra line-search evaluations per Newton iteration (tuning knob)
   int warm;        // start the solver from the previous evaluation's qacc (tuning knob)
+  int fast;        // allow the feet-only straight-line solver instantiation (tuning knob / A-B tests; results agree to rounding)
 };
 
 }  // namespace rex

@@ -54,7 +54,10 @@ extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build 
 #if defined(REX_WAVETIME)
 // diagnostic build only: cycles every wave of the last planar / humanoid step launch spent in its substeps (the kernel time at
 // B = 32 768 is the SLOWEST wave's, not the average)
-namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; __device__ unsigned long long g_wavehum[1024][16]; }
+namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; __device__ unsigned long long g_wavehum[1024][16];
+                __device__ unsigned long long g_wavephase[8192][4]; }   // planar step kernel: cycles entry -> state loaded -> substeps done -> outputs stored -> fused reset done
+extern "C" int rex_debug_wavephase(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavephase), sizeof(unsigned long long) * 4 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1; }
 extern "C" int rex_debug_wavehum(unsigned long long* out) {   // humanoid: per-wave phase accumulators of the last launch (-DREX_KTIME -DREX_WAVETIME)
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavehum), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -1; }
 extern "C" int rex_debug_waveinfo(unsigned long long* out, int n) {   // n waves x 8 counters, then zeroed
@@ -265,13 +268,25 @@ template <class S>
 __device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepFlags& fl, const DRParams& dr, int resample,
                                                   int reset_state, unsigned i, float* __restrict__ obs);
 
+// Register budget of the planar step kernel: waves per SIMD the allocator must leave room for (512 registers per lane and
+// SIMD: 1 wave -> 512, 2 -> 256, 3 -> 168, 4 -> 128).  A lone wave issues one VALU instruction per 4 cycles, the SIMD one
+// per 2: the step kernel is VALU-issue bound (PMC: 1.0 quad-cycle per VALU instruction), so two narrower co-resident waves
+// beat one wide one as long as the live state fits.
+#ifndef REX_STEP_WAVES
+#define REX_STEP_WAVES 1
+#endif
+#define REX_STEP_OCC __attribute__((amdgpu_waves_per_eu(REX_STEP_WAVES, REX_STEP_WAVES)))
+
 template <class S>
-__global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
+__global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
                                                          SolParams<float> sp, const float* __restrict__ action,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          unsigned char* __restrict__ done_out,
                                                          unsigned char* __restrict__ trunc_out, float* __restrict__ term_obs,
                                                          DRParams dr, int fused_reset, int resample) {
+#if defined(REX_WAVETIME)
+  const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   const long long B = s.B;
@@ -297,7 +312,8 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[5], __builtin_amdgcn_s_memtime() - tk0);
 #endif
 #if defined(REX_WAVETIME)
-  if ((threadIdx.x & 63) == 0) g_wavetime[blockIdx.x & 8191] = __builtin_amdgcn_s_memtime() - tk0;
+  const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) g_wavetime[blockIdx.x & 8191] = tk1 - tk0;
 #endif
   const float dx = q[0];
   q[0] = x_before + dx;
@@ -343,6 +359,7 @@ __global__ void __launch_bounds__(64) planar_step_kernel(DevState s, StepFlags f
   if (fused_reset && d) planar_reset_lane<S>(s, fl, dr, resample, 1, i, obs);
 #if defined(REX_WAVETIME)
   if ((threadIdx.x & 63) == 0) { g_waveinfo[blockIdx.x & 8191][1] += __builtin_amdgcn_s_memtime() - tr0; }   // slot 1 ("iters", unused): cycles in the fused reset
+  if ((threadIdx.x & 63) == 0) { unsigned long long* ph = g_wavephase[blockIdx.x & 8191]; ph[0] = tk0 - tp0; ph[1] = tk1 - tk0; ph[2] = tr0 - tk1; ph[3] = __builtin_amdgcn_s_memtime() - tr0; }
 #endif
 }
 
@@ -353,6 +370,13 @@ __device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepF
                                                   int reset_state, unsigned i, float* __restrict__ obs) {
   const long long B = s.B;
   unsigned ep = s.episode[i] + 1; s.episode[i] = ep;
+#if defined(REX_DIAG_CHEAP_RESET)   // timing diagnostics only: what the RNG work of the fused reset costs the step kernel
+  if (reset_state) {
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = (k == 1 && S::KIND != 2) ? 1.25f : 0.0f; (s.qvel + (size_t)k * B)[i] = 0.0f; });
+    s.t[i] = 0; s.done[i] = 0;
+  }
+  return;
+#endif
   if (reset_state) {
     rocrand_state_philox4x32_10 st;
     rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
@@ -649,7 +673,7 @@ static void sp_to_float(const SolParams<double>& a, SolParams<float>& b) {
   b.con_K = (float)a.con_K; b.con_B = (float)a.con_B; b.con_dmin = (float)a.con_dmin; b.con_dmax = (float)a.con_dmax;
   b.con_width = (float)a.con_width; b.con_margin = (float)a.con_margin; b.lim_K = (float)a.lim_K; b.lim_B = (float)a.lim_B;
   b.lim_dmin = (float)a.lim_dmin; b.lim_dmax = (float)a.lim_dmax; b.lim_width = (float)a.lim_width; b.meaninertia = (float)a.meaninertia;
-  b.ls_max = a.ls_max; b.warm = a.warm;
+  b.ls_max = a.ls_max; b.warm = a.warm; b.fast = a.fast;
 }
 
 template <class S>
@@ -779,6 +803,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
   if (getenv("REX_LS_MAX")) h->sp.ls_max = atoi(getenv("REX_LS_MAX"));   // tuning knobs
   if (getenv("REX_WARM")) h->sp.warm = atoi(getenv("REX_WARM"));
+  if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);

@@ -46,6 +46,17 @@ def host_step(kind, f32, qpos, qvel, action, xi, nsub):
     return qo.T.copy(), vo.T.copy(), cap
 
 
+def set_fast(flag):
+    """SolParams.fast of the following calls: 1 = the feet-only straight-line solver instantiation is allowed (default),
+    0 = general instantiation only."""
+    lib().ph_set_fast(int(flag))
+
+
+def last_mode():
+    """solver instantiation the last host_forward entered: 0 no rows, 1 general, 2 general + self rows, 3 feet-only"""
+    return lib().ph_last_mode()
+
+
 def host_forward(kind, f32, qpos, qvel, action, xi):
     L = lib(); nv = len(qvel)
     q = np.ascontiguousarray(qpos, dtype=np.float64); v = np.ascontiguousarray(qvel, dtype=np.float64)

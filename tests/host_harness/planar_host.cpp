@@ -8,6 +8,11 @@
 
 using namespace rex;
 
+static int g_fast = 1;   // SolParams::fast of every call below: 1 = allow the feet-only straight-line solver, 0 = general path only
+static int g_last_mode = -1;   // SolveStats::mode of the last ph_forward
+extern "C" void ph_set_fast(int f) { g_fast = f; }
+extern "C" int ph_last_mode() { return g_last_mode; }
+
 template <class T, class S>
 static void run_step(int n, int nsub, const double* qpos, const double* qvel, const double* act, const double* xi,
                      const double* size, double* qpos_out, double* qvel_out, int* capped) {
@@ -23,6 +28,7 @@ static void run_step(int n, int nsub, const double* qpos, const double* qvel, co
       T s4[4] = {x[7], x[8], x[9], x[10]};
       derive_model<T, S>(s4, G, nominal, sp);
     }
+    sp.fast = g_fast;
     LaneParams<T, S> P; lane_params(S{}, x, P);
     bool cap = false; T acc[S::NV];
     for (int k = 0; k < S::NV; k++) acc[k] = T(0);
@@ -43,12 +49,13 @@ static void run_forward(const double* qpos, const double* qvel, const double* ac
   for (int k = 0; k < S::NXI; k++) x[k] = T(xi[k]);
   if (S::KIND == 3) { sz[0] = x[7]; sz[1] = x[8]; sz[2] = x[9]; sz[3] = x[10]; }
   derive_model<T, S>(sz, G, nominal, sp);
+  sp.fast = g_fast;
   LaneParams<T, S> P; lane_params(S{}, x, P);
   for (int i = 0; i < S::NV; i++) for (int j = 0; j < S::NV; j++) M[i][j] = T(0);
   SolveStats st = forward<T, S>(q, v, c, G, P, sp, a, M);
   for (int k = 0; k < S::NV; k++) qacc[k] = double(a[k]);
   for (int i = 0; i < S::NV; i++) for (int j = 0; j < S::NV; j++) Mout[i * S::NV + j] = double(j <= i ? M[i][j] : M[j][i]);
-  *iters = st.iters;
+  *iters = st.iters; g_last_mode = st.mode;
 }
 
 template <class T, class S>

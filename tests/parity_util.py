@@ -56,3 +56,22 @@ def lanes_per_block(n):
             os.environ.pop("REX_LANES", None)
         else:
             os.environ["REX_LANES"] = old
+
+
+@contextlib.contextmanager
+def create_knobs(**knobs):
+    """Environment knobs librex reads once in rex_create (REX_FAST, REX_LANES, ...) for the handles created inside."""
+    old = {k: os.environ.get(k) for k in knobs}
+    try:
+        for k, v in knobs.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

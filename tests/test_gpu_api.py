@@ -15,20 +15,34 @@ def torch_mod():
     return torch
 
 
+@pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("batch", [1, 7, 100, 4097])
-def test_ragged_batches_match_full_lanes(torch_mod, batch):
-    """lane i of a ragged batch computes exactly what lane i of a big batch computes (global-index RNG,
-    no cross-lane coupling): covers the partial last wavefront."""
+def test_ragged_batches_match_full_lanes(torch_mod, batch, fast):
+    """lane i of a ragged batch computes what lane i of a big batch computes (global-index RNG, no cross-lane data flow):
+    covers the partial last wavefront.  With the solver knob REX_FAST=0 the arithmetic of a lane does not depend on its
+    wave at all -> bit-identical.  By default the WAVE picks the solver instantiation (feet-only straight-line / general /
+    skip of the qacc_smooth factorisation on warm starts): every choice converges to the same unique minimiser, so lanes
+    agree to fp32 rounding instead, and everything the RNG decides (reset states, xi) stays bit-identical."""
     import random_envs_amd as rex
+    from parity_util import create_knobs
     torch = torch_mod
-    big = rex.make("RandomHopper-v0", batch=8192, seed=7, autoreset=False)
-    small = rex.make("RandomHopper-v0", batch=batch, seed=7, autoreset=False)
+    with create_knobs(REX_FAST=fast):
+        big = rex.make("RandomHopper-v0", batch=8192, seed=7, autoreset=False)
+        small = rex.make("RandomHopper-v0", batch=batch, seed=7, autoreset=False)
     for e in (big, small):
-        e.set_dr_distribution("uniform", [3.0, 4.0, 3.5, 4.5, 2.2, 3.2, 4.5, 5.5]); e.set_dr_training(True); e.reset()
+        e.set_dr_distribution("uniform", [3.0, 4.0, 3.5, 4.5, 2.2, 3.2, 4.5, 5.5]); e.set_dr_training(True)
+        ob0 = e.reset().clone()
+        if e is big:
+            ref0 = ob0
+    assert torch.equal(ref0[:batch], ob0) and torch.equal(big.get_task()[:batch], small.get_task())
     a = torch.rand(8192, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1
     for _ in range(3):
         ob, rb, db, _ = big.step(a); os_, rs, ds, _ = small.step(a[:batch])
-        assert torch.equal(ob[:batch], os_) and torch.equal(rb[:batch], rs) and torch.equal(db[:batch], ds)
+        if fast:
+            assert torch.allclose(ob[:batch], os_, rtol=2e-5, atol=2e-6) and torch.allclose(rb[:batch], rs, rtol=1e-4, atol=1e-4)
+            assert torch.equal(db[:batch], ds)
+        else:
+            assert torch.equal(ob[:batch], os_) and torch.equal(rb[:batch], rs) and torch.equal(db[:batch], ds)
     big.close(); small.close()
 
 
@@ -134,5 +148,5 @@ def test_sb3_style_adapter(torch_mod):
         for i in np.nonzero(dones)[0]:
             assert infos[i]["terminal_observation"].shape == (11,) and "TimeLimit.truncated" in infos[i]
             seen += 1
-    assert seen > 0 and venv.get_attr("task_dim") == [4]
+    assert seen > 0 and venv.get_attr("task_dim") == [4] * 128 and venv.get_attr("task_dim", indices=[0]) == [4]
     venv.close()

@@ -258,8 +258,13 @@ def test_replay_transitions_every_chain(torch_mod, eid):
     assert env2.autoreset                                                     # restored
     env.set_task(xi); env.set_state(q, v)
     ref, rr, dd, _ = env.step(a)
-    if hum:   # absolute x, y enter through rounding only (com-based quantities): tight, not bitwise
-        err = ((nxt - ref).abs() / (1 + ref.abs())).max().item()
+    if hum:
+        # The dynamics do not depend on the dropped root x, y: qpos[2:], qvel and qfrc_actuator agree to rounding.  The
+        # cinert / cvel blocks DO move with the absolute position once the masses are randomised -- MuJoCo refers them to
+        # the subtree COM, which divides sum(m_i x_i) by the compile-time subtree mass that set_task never refreshes
+        # (SURVEY Q4); the oracle restates the same quirk (oracle/mjo_core.c::mjo_com_quantities).
+        inv = list(range(45)) + list(range(269, 292))
+        err = ((nxt[:, inv] - ref[:, inv]).abs() / (1 + ref[:, inv].abs())).max().item()
         assert err < 2e-4, err
         assert (r - rr).abs().max().item() < 2e-2 and (d != dd).float().mean().item() < 0.01
     else:     # the planar kernels integrate from x = 0 anyway: bit-identical

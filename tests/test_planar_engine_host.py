@@ -4,7 +4,7 @@ reduction itself, fp32 instantiation gives the tolerance the GPU tests use."""
 import numpy as np
 import pytest
 
-from host_harness.build import host_constants, host_forward, host_step
+from host_harness.build import host_constants, host_forward, host_step, last_mode, set_fast
 from oracle_bindings import (DIMS, oracle_batch_step, oracle_constants, oracle_contacts, oracle_forward,
                              rollout_states)
 from random_envs_amd.specs import SPECS
@@ -97,3 +97,31 @@ def test_walker_compact_geometry_table():
         err = ctypes.c_double()
         worst = L.ph_walker_compact_check(size.ctypes.data_as(D), nom.ctypes.data_as(D), ctypes.byref(err))
         assert err.value < 1e-15, (worst, err.value, size)   # rounding of zero offsets
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fast_and_general_solver_instantiations_agree(kind):
+    """The feet-only straight-line solver instantiation (forward(): mode 3) and the general one are the same Newton
+    method over the same rows: on states where only the feet touch they agree to rounding in fp64 and to the fp32
+    tolerance in fp32; states with other contacts never enter the fast path (identical results)."""
+    d = DIMS[kind]
+    q, v, xi = rollout_states(kind, 400, steps_max=50, seed=8)
+    a = np.random.RandomState(2).uniform(-1, 1, (400, d["nu"]))
+    try:
+        set_fast(1); qf, vf, _ = host_step(kind, False, q, v, a, xi, d["frame_skip"]); q32f, v32f, _ = host_step(kind, True, q, v, a, xi, d["frame_skip"])
+        set_fast(0); qg, vg, _ = host_step(kind, False, q, v, a, xi, d["frame_skip"]); q32g, v32g, _ = host_step(kind, True, q, v, a, xi, d["frame_skip"])
+    finally:
+        set_fast(1)
+    e = np.abs(vf - vg).max(1) / (1 + np.abs(vg).max(1))
+    assert e.max() < 1e-9 and np.abs(qf - qg).max() < 1e-11, (e.max(), np.abs(qf - qg).max())
+    # the fast path IS what ran: single forward evaluations report the instantiation they entered
+    modes = {0: 0, 1: 0, 2: 0, 3: 0}
+    for i in range(0, 400, 4):
+        qa, _, _ = host_forward(kind, False, q[i], v[i], a[i], xi[i]); m = last_mode(); modes[m] += 1
+        set_fast(0)
+        qb, _, _ = host_forward(kind, False, q[i], v[i], a[i], xi[i]); assert last_mode() in ((0, 2) if m in (0, 2) else (1,))
+        set_fast(1)
+        assert np.abs(qa - qb).max() <= 1e-9 * (1 + np.abs(qb).max())
+    assert modes[3] > 30, modes
+    e32 = np.abs(v32f - v32g).max(1) / (1 + np.abs(v32g).max(1))
+    assert np.percentile(e32, 99) < 2e-4 and np.abs(q32f - q32g).max() < 2e-5
