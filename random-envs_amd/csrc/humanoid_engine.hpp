@@ -35,8 +35,13 @@ constexpr int NJNT = 18;    // free + 17 hinges
 constexpr int NQ = 24, NV = 23, NU = 17;
 constexpr int NGEOM = 18;   // floor + 17 body geoms
 constexpr int MAXPAIR = 128;
-constexpr int MAXCON = 24;  // contacts kept per evaluation
-constexpr int MAXEFC = 64;  // constraint rows kept per evaluation
+// Row storage is sized to what the MODEL can produce, so nothing is ever dropped in practice (the reference's MuJoCo keeps
+// every row: its own caps, nconmax 100 / njmax 500 by default, are out of this model's reach as well): 17 limit rows +
+// 33 floor contacts (16 capsules x 2 ends + the head sphere) x 4 pyramid rows + a few capsule-capsule rows.  A lying,
+// crumpled humanoid (tests/test_gpu_humanoid.py::test_pile_up_states) reaches 26 contacts / 108 rows.  Rows beyond the
+// arrays would still be dropped and counted (`overflow`); the tests require the counter to stay 0.
+constexpr int MAXCON = 64;   // contacts per evaluation (a counter on the device; the contact log exists on the host only)
+constexpr int MAXEFC = 192;  // constraint rows per evaluation
 constexpr int NXI = 30, NOBS = 376;
 enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
 // dual-space PGS working set kept in LDS on the device (one contiguous column per lane): the packed lower triangle of
@@ -225,7 +230,9 @@ template <> struct HostColumn<float> {};
 
 template <class T>
 struct Scratch {   // runtime-indexed per-lane arrays (HIP scratch): contacts and constraint rows
-  T cpos[MAXCON][3], cdist[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];   // contact log (written, never read back by the engine)
+#if !defined(__HIP_DEVICE_COMPILE__)
+  T cpos[MAXCON][3], cdist[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];   // contact log: host builds only (tests); the engine never reads it
+#endif
   T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
   // parked between phases (plain stores / loads at fixed offsets; keeps them out of the register file while the solver runs)
   T obs_cinert[NBODY][10], obs_cvel[NBODY][6], obs_xipos_x[NBODY], obs_qfrc_actuator[NV];   // observation inputs
@@ -474,11 +481,15 @@ template <class T>
 REX_HD void add_contact(Kin<T>& K, Scratch<T>& s, const Model<T>& m, const T* qvel, const PairRec<T>& pr, T dist, const T* pos, const T* normal, const T* yaxis) {
   if (K.ncon >= MAXCON) { K.overflow = 1; return; }
   int c = K.ncon++;
+#if !defined(__HIP_DEVICE_COMPILE__)
   s.cdist[c] = dist; s.cdim[c] = pr.dim; s.cb1[c] = pr.b1; s.cb2[c] = pr.b2;
+  for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
+#else
+  (void)c;
+#endif
   T f[9];
   for (int k = 0; k < 3; k++) { f[k] = normal[k]; f[3 + k] = yaxis ? yaxis[k] : T(0); f[6 + k] = 0; }
   make_frame(f);
-  for (int k = 0; k < 3; k++) s.cpos[c][k] = pos[k];
   if (!(dist < m.margin)) return;
   int ne = K.nefc;
   const T tran = pr.tran, mu = pr.mu;

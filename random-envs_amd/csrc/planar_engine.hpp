@@ -550,7 +550,10 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
   // (have_a0: qacc_smooth was computed -- cold starts, and every solve when the `fast` knob is off: then a lane without rows
   // leaves with qacc_smooth itself and its arithmetic does not depend on what the other lanes of its wave are doing.)
   const bool has_rows = C.any || (SELF && R.mask != 0u);
-  static_for<0, S::NV>([&](auto II) { qacc[II] = have_a0 ? ((warm && has_rows) ? qacc[II] : qacc_smooth[II]) : qacc[II]; });
+  // (opaque: left alone, LLVM turns this select between two arrays into a select of POINTERS, which keeps both arrays in
+  // scratch memory and costs a dependent ~500-cycle scratch round trip per solve)
+  static_for<0, S::NV>([&](auto II) { T prev = qacc[II], cold = qacc_smooth[II]; opaque(prev); opaque(cold);
+                                      qacc[II] = have_a0 ? ((warm && has_rows) ? prev : cold) : prev; });
   SolveStats st{0, false, 0};
   // stop when the force residual |M a - f - J^T f_c| is at rounding level relative to the forces
   // that balance in it (the piecewise-quadratic cost makes Newton exact once the active set is right)

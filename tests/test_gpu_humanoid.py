@@ -194,7 +194,7 @@ def test_humanoid_unmodeled_id(torch_mod):
 
 def test_pile_up_states_all_solver_paths(torch_mod):
     """Humanoids lying / crouching on the floor with hinges past their limits: row counts beyond the in-LDS sweep sizes
-    (> 16, > 21 -> scratch-row fallback).  One forward evaluation (set_state -> sim.forward) and one env step vs the oracle."""
+    (> 16, > 21 -> scratch-row fallback) and beyond round 1's 64-row cap.  One env step vs the oracle, every lane."""
     import random_envs_amd as rex
     from oracle_bindings import oracle_humanoid_step
     from random_envs_amd.specs import SPECS
@@ -214,11 +214,17 @@ def test_pile_up_states_all_solver_paths(torch_mod):
     _, vv = env.get_state()
     vv = vv.cpu().numpy().astype(np.float64)
     ok = np.isfinite(ref["qvel"]).all(1)
-    ev = np.abs(vv - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    vs = 1 + np.abs(ref["qvel"]).max(1)
+    ev = np.abs(vv - ref["qvel"]).max(1) / vs
     c = env.counters()
-    # About a tenth of these states need more contacts / rows than the engine keeps (MAXCON 24 / MAXEFC 64: the `overflow`
-    # counter), where it intentionally differs from the oracle; every other env has to agree to fp32 rounding
-    # (host fp32 build of the same code: median 5e-7, p90 1e-6 on the envs that keep all their rows).
-    assert c["nonfinite"] <= 0.02 * n and c["overflow"] > 0
-    assert np.median(ev[ok]) < 1e-5 and np.mean(ev[ok] < 1e-4) > 0.80, (np.median(ev[ok]), np.mean(ev[ok] < 1e-4))
+    # Row storage is sized to the model (MAXCON 64 / MAXEFC 192; these states reach 26 contacts / 108 rows): nothing is
+    # dropped, so EVERY lane the oracle itself keeps finite has to agree -- to fp32 rounding, or as far as the oracle's own
+    # conditioning explains (deep penetrations under 50 capped PGS sweeps amplify input rounding by orders of magnitude).
+    assert c["overflow"] == 0, c
+    assert np.isfinite(vv[ok]).all() and c["nonfinite"] <= (~ok).sum()
+    from oracle_bindings import oracle_sensitivity
+    from parity_util import assert_lanes_explained
+    _, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_humanoid_step(q_, v_, a_, x_), [q, v, a, xi], ["qvel"], trials=2)
+    assert np.median(ev[ok]) < 1e-5, np.median(ev[ok])
+    assert_lanes_explained(ev[ok], (sens["qvel"] / vs)[ok], 1e-4, 5e-1, K=256.0, label="humanoid pile-ups |dqvel|rel")
     env.close()

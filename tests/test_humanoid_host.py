@@ -96,11 +96,12 @@ def test_forward_dynamics_pile_ups(hh):
         O.mjo_humanoid_probe(_p(q), _p(v), _p(a), _p(xi), None, _p(qa_o), _p(M_o), ctypes.byref(nc), ctypes.byref(ne), ctypes.byref(it), None, None, 0)
         qa_h = np.zeros(23); M_h = np.zeros((23, 23)); info = np.zeros(4, dtype=np.int32)
         hh.hh_forward(0, _p(q), _p(v), _p(a), _p(xi), _p(qa_h), _p(M_h), info.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
-        if info[3] or ne.value > 64: continue                               # dropped rows (MAXCON / MAXEFC): not comparable
+        assert info[3] == 0, (k, "rows dropped", nc.value, ne.value)       # storage is sized to the model: nothing is ever dropped
         assert info[0] == nc.value and info[1] == ne.value, (k, info, nc.value, ne.value)
         seen["le16" if ne.value <= 16 else ("17_21" if ne.value <= 21 else "gt21")] += 1
+        seen["gt64"] = seen.get("gt64", 0) + (ne.value > 64)
         worst = max(worst, np.abs(qa_o - qa_h).max() / (1 + np.abs(qa_o).max()))
-    assert min(seen.values()) >= 3, seen
+    assert min(seen.values()) >= 3, seen                                    # incl. states beyond round 1's 64-row cap
     assert worst < 1e-8, worst
 
 
