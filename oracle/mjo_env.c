@@ -312,6 +312,7 @@ int mjo_model_constants(int kind, const double* size, double* body_mass, double*
     case MJO_ENV_HOPPER: mjo_build_hopper(m, size); break;
     case MJO_ENV_WALKER2D: mjo_build_walker2d(m, size); break;
     case MJO_ENV_HALFCHEETAH: mjo_build_halfcheetah(m, size); break;
+    case MJO_ENV_HUMANOID: mjo_build_humanoid(m); break;
     default: free(m); return -1;
   }
   for (int b = 0; b < m->nbody; b++) {
