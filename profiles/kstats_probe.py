@@ -1,5 +1,5 @@
 import os, sys, ctypes
-os.environ["REX_LIB"]="librex_hip_kstats.so"
+os.environ.setdefault("REX_LIB","librex_hip_kstats.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, random_envs_amd as rex
 from random_envs_amd import _native

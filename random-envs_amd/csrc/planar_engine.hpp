@@ -481,6 +481,21 @@ REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const
       if (REX_WAVE_ANY((possible >> p) & 1u)) {   // pairs whose bounding circles are apart in every lane cost nothing
         T p1[2], a1[2], p2[2], a2[2], l1, l2;
         capsule_pose<T, S, ga>(K, G, p1, a1, l1); capsule_pose<T, S, gb>(K, G, p2, a2, l2);
+        // Second cull: separating axes of the two SEGMENTS (each axis and its normal), inflated by r1 + r2 + margin.  The
+        // bounding circles of two long thin capsules overlap for most of a folded leg's range without the capsules being
+        // anywhere near each other, and a wave that gets past the cull pays the whole narrow phase -- the launch ends with
+        // its slowest wave.  Any axis with a gap > R is a certificate that no point pair is within R (conservative).
+        {
+          const T R = G.radius[ga] + G.radius[gb] + sp.con_margin;
+          const T dx = p2[0] - p1[0], dz = p2[1] - p1[1];
+          const T cr = abs_t(a1[0] * a2[1] - a1[1] * a2[0]), dt = abs_t(a1[0] * a2[0] + a1[1] * a2[1]);
+          const T s1 = abs_t(-a1[1] * dx + a1[0] * dz) - l2 * cr;          // normal of segment 1
+          const T s2 = abs_t(-a2[1] * dx + a2[0] * dz) - l1 * cr;          // normal of segment 2
+          const T t1 = abs_t(a1[0] * dx + a1[1] * dz) - l1 - l2 * dt;      // along segment 1
+          const T t2 = abs_t(a2[0] * dx + a2[1] * dz) - l2 - l1 * dt;      // along segment 2
+          const bool apart = s1 > R || s2 > R || t1 > R || t2 > R;
+          if (!REX_WAVE_ANY(((possible >> p) & 1u) && !apart)) return;     // (return from this pair's lambda)
+        }
         Hit2<T> H;
         capsule_capsule_2d(p1, a1, l1, G.radius[ga], p2, a2, l2, G.radius[gb], sp.con_margin, H);
         static_for<0, 2>([&](auto KK) {
