@@ -121,6 +121,9 @@ def main():
                     help="second workload (SURVEY 8 f2): ONE logged transition replayed under a fresh candidate xi per env and step "
                          "(set_task + set_sim_state + step, no auto-reset)")
     ap.add_argument("--counter-every", type=int, default=256, help="steps between asynchronous all-reduces of the step counter")
+    ap.add_argument("--settle", type=int, default=300,
+                    help="untimed steps before the warm-up: right after reset every env is in the same phase of its first episode "
+                         "(in the air, no contact rows -- cheaper than the steady state where episodes end and restart all the time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the per-launch HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the launch path on one GPU)")
@@ -179,6 +182,9 @@ def main():
 
     # every one-time cost goes BEFORE the timed region: the HIP-event pool is created here and the warm-up launches
     # are already timing-enabled (the first timed hipEventRecord on a stream pays a one-off profiling set-up)
+    for k in range(0 if args.replay else args.settle):
+        one_step(k)
+    torch.cuda.synchronize()
     t_setup0 = time.perf_counter()
     env.enable_timing(not args.no_kernel_timing)
     one_step(0)

@@ -148,7 +148,7 @@ REX_HD void sym_matvec(const T (&M)[S::NV][S::NV], const T (&x)[S::NV], T (&y)[S
   });
 }
 
-// In-place sparse L^T D L factorisation (Featherstone): after the call H[k][k] = D_k and
+// In-place sparse L^T D L factorisation (Featherstone): after the call H[k][k] = 1 / D_k (the solve multiplies) and
 // H[k][i] (i ancestor dof of k) = L_ki.  Branch-induced zeros of the tree are never touched,
 // and H = M + J^T D J keeps M's sparsity because every constraint row lives on one root path.
 template <class T, class S>
@@ -156,6 +156,7 @@ REX_HD void ldl_factor(T (&H)[S::NV][S::NV]) {
   static_rfor<1, S::NV>([&](auto KK) {
     constexpr int k = KK;
     T inv = rcp_t(H[k][k]);
+    H[k][k] = inv;
     static_rfor<0, k>([&](auto II) {   // ancestors of k, deepest first
       constexpr int i = II;
       if constexpr (dof_coupled<S>(k, i)) {   // i < k and coupled  <=>  i is an ancestor dof of k
@@ -168,6 +169,7 @@ REX_HD void ldl_factor(T (&H)[S::NV][S::NV]) {
       }
     });
   });
+  H[0][0] = rcp_t(H[0][0]);
 }
 template <class T, class S>
 REX_HD void ldl_solve(const T (&H)[S::NV][S::NV], T (&b)[S::NV]) {
@@ -175,7 +177,7 @@ REX_HD void ldl_solve(const T (&H)[S::NV][S::NV], T (&b)[S::NV]) {
     constexpr int k = KK;
     static_for<0, k>([&](auto II) { constexpr int i = II; if constexpr (dof_coupled<S>(k, i)) b[i] -= H[k][i] * b[k]; });
   });
-  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; b[k] = b[k] * rcp_t(H[k][k]); });
+  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; b[k] = b[k] * H[k][k]; });
   static_for<1, S::NV>([&](auto KK) {
     constexpr int k = KK;
     static_for<0, k>([&](auto II) { constexpr int i = II; if constexpr (dof_coupled<S>(k, i)) b[k] -= H[k][i] * b[i]; });
@@ -186,7 +188,10 @@ REX_HD void ldl_solve(const T (&H)[S::NV][S::NV], T (&b)[S::NV]) {
 template <class T>
 REX_HD T impedance(T dmin, T dmax, T width, T x_abs) {
   T x = x_abs * rcp_t(width);
-  T y = x < T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
+  // both arms computed, then ONE select: written as a ternary over expressions the compiler emits a divergent branch
+  // (s_and_saveexec / s_xor / s_or exec around three instructions, ~13 of them per evaluation)
+  const T ya = T(2) * x * x, t1 = T(1) - x, yb = T(1) - T(2) * t1 * t1;
+  T y = x < T(0.5) ? ya : yb;
   T imp = dmin + y * (dmax - dmin);
   imp = x >= T(1) ? dmax : imp;
   return (dmin == dmax) ? dmin : imp;
@@ -525,6 +530,17 @@ REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const
 #define REX_MARK(name) ((void)0)
 #endif
 
+#if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
+// diagnostic build only: cycles per phase of forward(), summed per wave (lane 0) with fire-and-forget atomics.  The stamp
+// takes a value the phase produced as an input, so that value is complete before the clock is read.
+extern __device__ unsigned long long g_evalphase[8192][8];
+#define REX_PSTAMP(var, dep) unsigned long long var; { float dep_ = (float)(dep); asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : "v"(dep_) : "memory"); }
+#define REX_PACC(slot, t0, t1) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_evalphase[blockIdx.x & 8191][slot], (t1) - (t0)); } while (0)
+#else
+#define REX_PSTAMP(var, dep) ((void)0)
+#define REX_PACC(slot, t0, t1) ((void)0)
+#endif
+
 struct SolveStats { int iters; bool capped; int mode; };   // mode: solver instantiation forward() entered (0 none, 1 general, 2 general + self rows, 3 feet-only straight-line)
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; };
@@ -583,15 +599,22 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
   // straight-line instantiation: hinge columns of the point Jacobians once per solve; J qacc of pass 1 is reused by pass 2
   T Jt[BR ? 1 : NC][S::NB], Jn[BR ? 1 : NC][S::NB], lt[NC], ln[NC];
   if constexpr (!BR) for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; point_jac<T, S, S::geom_body[k / 2]>(K, C.px[k], C.pz[k], Jt[k], Jn[k]); });
-  for (int it = 0; it < MAXIT; ++it) {
+  T Ma[S::NV];   // M qacc: formed once, then carried along the accepted steps (Ma += alpha * M sr)
+  sym_matvec<T, S>(M, qacc, Ma);
+#if defined(REX_DIAG_MAXIT)   // timing diagnostics only (wrong results): cap the Newton iterations of every solve
+  const int maxit = REX_DIAG_MAXIT;
+#else
+  constexpr int maxit = MAXIT;
+#endif
+  for (int it = 0; it < maxit; ++it) {
     if (!REX_WAVE_ANY(!lane_done)) break;
     T cpx[NC], cpz[NC];   // per-iteration opaque copies of the contact points (see opaque())
     if constexpr (BR) for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; cpx[k] = C.px[k]; cpz[k] = C.pz[k]; opaque(cpx[k]); opaque(cpz[k]); });
     REX_COUNT(pass1, 1);
     REX_MARK("pass1");
+    REX_PSTAMP(s_0, qacc[0]);
     // ---- pass 1: gradient and active edges --------------------------------------------------
-    T g[S::NV], Ma[S::NV];
-    sym_matvec<T, S>(M, qacc, Ma);
+    T g[S::NV];
     T fref = T(0);
     static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] = Ma[i] - qfrc_smooth[i]; fref += Ma[i] * Ma[i] + qfrc_smooth[i] * qfrc_smooth[i]; });
     unsigned lim_on = 0, e1 = 0, e2 = 0, e3 = 0, self_on = 0;
@@ -646,6 +669,8 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     p_lim = lim_on; p_e1 = e1; p_e2 = e2; p_e3 = e3; p_self = self_on;
     lane_done = lane_done || same_set || !(gn > tol2 * fref);   // NaN counts as done
     if (!REX_WAVE_ANY(!lane_done)) break;
+    REX_PSTAMP(s_1, gn);
+    REX_PACC(5, s_0, s_1);
     REX_COUNT(pass2, 1);
     REX_MARK("pass2_hess");
     // ---- pass 2: Hessian of the current active set, Newton direction ------------------------
@@ -767,11 +792,13 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     const bool exact_step = a == T(1) && m_lim == lim_on && m_e1 == e1 && m_e2 == e2 && m_e3 == e3 && m_self == self_on;
     a = lane_done ? T(0) : a;
     T amax = T(0), smax = T(0);
-    static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; amax = max_t(amax, abs_t(qacc[II])); smax = max_t(smax, abs_t(a * sr[II])); });
+    static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; Ma[II] += a * Ms[II]; amax = max_t(amax, abs_t(qacc[II])); smax = max_t(smax, abs_t(a * sr[II])); });
 #if defined(REX_DEBUG_SOLVER) && !defined(__HIP_DEVICE_COMPILE__)
     if (it >= 12) printf("     alpha %.6g smax %.3e amax %.3e d1 %.3e d0 %.3e\n", double(a), double(smax), double(amax), double(d1), double(d0));
 #endif
     lane_done = lane_done || exact_step || smax <= stag * (T(1) + amax);   // stagnation at rounding level
+    REX_PSTAMP(s_2, qacc[0] + amax);
+    REX_PACC(6, s_1, s_2);
     st.iters = it + 1;
     if (it == MAXIT - 1) st.capped = REX_WAVE_ANY(!lane_done);
   }
@@ -795,8 +822,10 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
                           bool warm = false) {
   REX_STAMP(t_0);
   REX_MARK("kinematics");
+  REX_PSTAMP(p_0, q[0]);
   Kin<T, S> K;
   kinematics<T, S>(q, G, K);
+  REX_PSTAMP(p_1, K.c[S::NB - 1] + K.A[S::NB - 1][0] + K.rc[S::NB - 1][1] + K.s[1]);
   REX_STAMP(t_1);
   T f[S::NV], a0[S::NV];
   {
@@ -809,11 +838,13 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
       f[j + 2] = -G.damping[j] * v[j + 2] - G.stiffness[j] * q[j + 2] - bias[j + 2] + T(S::gear[j - 1]) * c;
     });
   }
+  REX_PSTAMP(p_2, f[S::NV - 1] + f[0] + M[S::NV - 1][0] + M[2][2]);
   REX_STAMP(t_2);
   REX_STAMP(t_3);
   REX_MARK("detect");
   Constraints<T, S> C;
   detect_constraints<T, S>(q, v, G, sp, K, C);
+  REX_PSTAMP(p_3, C.dist[2 * S::NG - 1] + C.lD[S::NB - 1] + T(C.self_possible));
   REX_STAMP(t_4);
   SolveStats st{0, false, 0};
 #if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
@@ -860,6 +891,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
     ldl_solve<T, S>(L, a0);
   } else static_for<0, S::NV>([&](auto II) { a0[II] = T(0); });
   REX_MARK("dispatch");
+  REX_PSTAMP(p_4, a0[0] + T(R.mask));
   if (mode == 3) {
     REX_MARK("fast_rows");
     slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
@@ -874,6 +906,8 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   if (mode == 3 && (threadIdx.x & 63) == 0) atomicAdd(&g_kstats[7], 1ull);   // wave-solves on the fast path
 #endif
   REX_MARK("forward_end");
+  REX_PSTAMP(p_5, qacc[0] + qacc[S::NV - 1]);
+  REX_PACC(0, p_0, p_1); REX_PACC(1, p_1, p_2); REX_PACC(2, p_2, p_3); REX_PACC(3, p_3, p_4); REX_PACC(4, p_4, p_5);
   st.mode = mode;
   REX_STAMP(t_5);
   REX_TACC(0, t_0, t_1); REX_TACC(1, t_1, t_2); REX_TACC(2, t_2, t_3); REX_TACC(3, t_3, t_4); REX_TACC(4, t_4, t_5);

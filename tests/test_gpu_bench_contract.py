@@ -75,3 +75,15 @@ def test_two_rank_rehearsal_on_one_gpu():
     strong = _run(*common, "--batch", "4096", "--scaling", "strong", launcher=launcher)
     assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 4096
     assert "batch 2048 per GPU" in strong["config"]["workload"]
+
+
+def test_replay_workload_line():
+    """bench.py --replay: ONE logged transition replayed under a fresh candidate xi per env and step (set_task +
+    set_sim_state + step, device-resident, no auto-reset) -- the second massively parallel workload (SURVEY 8 f2,
+    random_hopper.py:128-152) -- with its own roofline entry (the xi row writes are part of its algorithmic bytes)."""
+    d = _run("--replay", "--steps", "50", "--warmup", "10", "--batch", "8192", "--no-cpu-baseline")
+    assert "replay" in d["config"]["workload"] and d["value"] > 1e6
+    r = d["roofline"]
+    assert r["bytes_per_env_step"] == 173 + 4 * 4 and r["traffic"] is None
+    assert abs(r["achieved"] - r["bytes_per_env_step"] * 8192 / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert d["nonfinite_lanes"] == 0
