@@ -397,7 +397,9 @@ template <class S> constexpr unsigned all_slots() { return (2 * S::NG >= 32) ? ~
 //   slot_rows<SLOTS>    impedance, regularisation and reference acceleration of the floor slots in SLOTS; with BR the
 //                       slots no lane of the wave touches are skipped by a wave-uniform branch, without BR the code is
 //                       straight-line (the fast path: a handful of slots, one basic block).
-template <class T, class S>
+// PAIR (two lanes per env): each lane tests ONE end of every capsule (end = lane parity) and keeps that end's data in the
+// even slot 2g; con_mask is exchanged and holds both ends' bits in both lanes.
+template <class T, class S, bool PAIR = false>
 REX_HD void detect_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const PlanarGeom<T, S>& G,
                                const SolParams<T>& sp, const Kin<T, S>& K, Constraints<T, S>& C) {
   unsigned lim_mask = 0, con_mask = 0;
@@ -419,6 +421,20 @@ REX_HD void detect_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const P
     }
   });
   // capsule ends against the floor plane z = 0
+  if constexpr (PAIR) {
+    const bool odd = pair_parity() != 0u;
+    static_for<0, S::NG>([&](auto GG) {
+      constexpr int g = GG; constexpr int b = S::geom_body[g]; constexpr int k = 2 * g;
+      T lx = odd ? G.e2[g][0] : G.e1[g][0], lz = odd ? G.e2[g][1] : G.e1[g][1];
+      T ox, oz; rot(K.c[b], K.s[b], lx, lz, ox, oz);
+      T cx = K.A[b][0] + ox, cz = K.A[b][1] + oz;
+      T dist = (cz + K.zroot) - G.radius[g];
+      if (dist < sp.con_margin) con_mask |= 1u << k;
+      C.px[k] = cx; C.pz[k] = T(0.5) * dist - K.zroot; C.dist[k] = dist;
+    });
+    con_mask <<= pair_parity();                  // own end's bits sit at 2g + parity
+    con_mask |= pair_xchg(con_mask);
+  } else
   static_for<0, S::NG>([&](auto GG) {
     constexpr int g = GG; constexpr int b = S::geom_body[g];
     static_for<0, 2>([&](auto EE) {
@@ -453,12 +469,13 @@ REX_HD void detect_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const P
   C.any = (lim_mask | con_mask) != 0u;
 }
 
-template <class T, class S, unsigned SLOTS, bool BR>
+template <class T, class S, unsigned SLOTS, bool BR, bool PAIR = false>
 REX_HD void slot_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const LaneParams<T, S>& P, const SolParams<T>& sp,
                       const Kin<T, S>& K, Constraints<T, S>& C) {
+  const unsigned par = PAIR ? pair_parity() : 0u;   // PAIR: SLOTS are the even slots 2g, the lane's own end is 2g + parity
   for_slots<SLOTS>([&](auto KK) {
     constexpr int k = KK; constexpr int g = k / 2; constexpr int b = S::geom_body[g];
-    const bool act = (C.con_mask >> k) & 1u;
+    const bool act = (C.con_mask >> (k + par)) & 1u;
     bool go = true;
     if constexpr (BR) go = REX_WAVE_ANY(act);
     if (go) {
@@ -569,7 +586,10 @@ enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4,
 // SLOTS: compile-time set of floor slots this instantiation looks at; BR: skip the slots no lane of the wave touches with
 // a wave-uniform branch (general path) or run them all straight-line (fast path: few slots, no branches in an iteration).
 template <bool BR> REX_HD bool any_lane(bool x) { if constexpr (BR) return REX_WAVE_ANY(x); else return true; }
-template <class T, class S, bool SELF, unsigned SLOTS, bool BR, int MAXIT = 24>
+// PAIR (two lanes per env, straight-line instantiation only): SLOTS are the even slots 2g of the feet; each lane runs the
+// per-slot part of both passes for ITS end (slot 2g + parity, data kept at index 2g) and the partial gradient / Hessian /
+// line-search sums and the active-edge bits are exchanged (pair_xchg); everything else is replicated.
+template <class T, class S, bool SELF, unsigned SLOTS, bool BR, bool PAIR = false, int MAXIT = 24>
 REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
                                const Kin<T, S>& K, const Constraints<T, S>& C, const SelfRows<T, S>& R,
                                const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, bool have_a0, int ls_max) {
@@ -596,6 +616,8 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
   unsigned p_lim = ~0u, p_e1 = ~0u, p_e2 = ~0u, p_e3 = ~0u, p_self = ~0u;
   bool lane_done = !has_rows && have_a0;
   constexpr int NC = 2 * S::NG;
+  static_assert(!PAIR || (!BR && !SELF), "PAIR: straight-line feet-only instantiation");
+  const unsigned par = PAIR ? pair_parity() : 0u;
   // straight-line instantiation: hinge columns of the point Jacobians once per solve; J qacc of pass 1 is reused by pass 2
   T Jt[BR ? 1 : NC][S::NB], Jn[BR ? 1 : NC][S::NB], lt[NC], ln[NC];
   if constexpr (!BR) for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; point_jac<T, S, S::geom_body[k / 2]>(K, C.px[k], C.pz[k], Jt[k], Jn[k]); });
@@ -618,6 +640,8 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     T fref = T(0);
     static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] = Ma[i] - qfrc_smooth[i]; fref += Ma[i] * Ma[i] + qfrc_smooth[i] * qfrc_smooth[i]; });
     unsigned lim_on = 0, e1 = 0, e2 = 0, e3 = 0, self_on = 0;
+    T gs[PAIR ? S::NV : 1];   // PAIR: this lane's slot contributions to the gradient
+    if constexpr (PAIR) static_for<0, S::NV>([&](auto II) { gs[II] = T(0); });
     static_for<1, S::NB>([&](auto JJ) {
       constexpr int j = JJ;
       if constexpr (S::limited[j]) {
@@ -630,7 +654,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     for_slots<SLOTS>([&](auto KK) {
       {
         constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
-        const bool act = (C.con_mask >> k) & 1u;
+        const bool act = (C.con_mask >> (k + par)) & 1u;
         if (any_lane<BR>(act)) {
           const T mu = P.mu[gg];
           T jt, jn;
@@ -638,13 +662,18 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           else { jdot_pre<T, S, b>(Jt[k], Jn[k], qacc, jt, jn); lt[k] = jt; ln[k] = jn; }
           T r1 = jn + mu * jt - (C.an[k] + C.at[k]), r2 = jn - mu * jt - (C.an[k] - C.at[k]), r3 = jn - C.an[k];
           bool s1 = act && r1 < T(0), s2 = act && r2 < T(0), s3 = act && r3 < T(0);
-          if (s1) e1 |= 1u << k; if (s2) e2 |= 1u << k; if (s3) e3 |= 1u << k;
+          if (s1) e1 |= 1u << (k + par); if (s2) e2 |= 1u << (k + par); if (s3) e3 |= 1u << (k + par);
           T f1 = s1 ? -C.D[k] * r1 : T(0), f2 = s2 ? -C.D[k] * r2 : T(0), f3 = s3 ? -C.D[k] * r3 : T(0);
           if constexpr (BR) jt_accum<T, S, b>(K, cpx[k], cpz[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
+          else if constexpr (PAIR) jt_accum_pre<T, S, b>(Jt[k], Jn[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), gs);
           else jt_accum_pre<T, S, b>(Jt[k], Jn[k], -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), g);
         }
       }
     });
+    if constexpr (PAIR) {   // both ends' contributions and active edges, identical in both lanes (commutative sums)
+      static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] += gs[i] + pair_xchg(gs[i]); });
+      e1 |= pair_xchg(e1); e2 |= pair_xchg(e2); e3 |= pair_xchg(e3);
+    }
     if constexpr (SELF && S::NSELF > 0) {
       static_for<0, 2 * S::NSELF>([&](auto PP) {
         constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
@@ -679,18 +708,24 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] = M[i][j]; }); });
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
       if constexpr (S::limited[j]) H[j + 2][j + 2] += ((lim_on >> j) & 1u) ? C.lD[j] : T(0); });
+    T Hs[PAIR ? S::NV : 1][PAIR ? S::NV : 1];   // PAIR: this lane's slot contributions to the Hessian
+    if constexpr (PAIR) static_for<0, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) Hs[i][j] = T(0); }); });
     for_slots<SLOTS>([&](auto KK) {
       {
         constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
-        const unsigned bit = 1u << k;
+        const unsigned bit = 1u << (k + par);
         if (any_lane<BR>(((e1 | e2 | e3) & bit) != 0u)) {
           const T mu = P.mu[gg];
           T s1 = (e1 & bit) ? T(1) : T(0), s2 = (e2 & bit) ? T(1) : T(0), s3 = (e3 & bit) ? T(1) : T(0);
           if constexpr (BR) hess_accum<T, S, b>(K, cpx[k], cpz[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), H);
+          else if constexpr (PAIR) hess_accum_pre<T, S, b>(Jt[k], Jn[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), Hs);
           else hess_accum_pre<T, S, b>(Jt[k], Jn[k], C.D[k] * mu * mu * (s1 + s2), C.D[k] * mu * (s1 - s2), C.D[k] * (s1 + s2 + T(2) * s3), H);
         }
       }
     });
+    if constexpr (PAIR) static_for<0, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] += Hs[i][j] + pair_xchg(Hs[i][j]); }); });
     if constexpr (SELF && S::NSELF > 0) {
       static_for<0, 2 * S::NSELF>([&](auto PP) {
         constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
@@ -738,10 +773,11 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           T x = lr + a * lv; bool on = ((C.lim_mask >> j) & 1u) && x < T(0);
           if (on) m_lim |= 1u << j;
           T dd = on ? C.lD[j] : T(0); d1 += dd * x * lv; d2 += dd * lv * lv; } });
+      T d1s = T(0), d2s = T(0);   // PAIR: this lane's slot part of phi', phi''
       for_slots<SLOTS>([&](auto KK) {
         {
           constexpr int k = KK; constexpr int gg = k / 2;
-          const bool act = (C.con_mask >> k) & 1u;
+          const bool act = (C.con_mask >> (k + par)) & 1u;
           if (any_lane<BR>(act)) {
             const T mu = P.mu[gg];
             const T jt = lt[k], jn = ln[k], vt = lvt[k], vn = lvn[k];
@@ -749,13 +785,17 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
             T v0 = vn + mu * vt, v1 = vn - mu * vt, v2 = vn;
             T x0 = r0 + a * v0, x1 = r1 + a * v1, x2 = r2 + a * v2;
             const bool o0 = act && x0 < T(0), o1 = act && x1 < T(0), o2 = act && x2 < T(0);
-            if (o0) m_e1 |= 1u << k; if (o1) m_e2 |= 1u << k; if (o2) m_e3 |= 1u << k;
+            if (o0) m_e1 |= 1u << (k + par); if (o1) m_e2 |= 1u << (k + par); if (o2) m_e3 |= 1u << (k + par);
             T w0 = o0 ? C.D[k] : T(0), w1 = o1 ? C.D[k] : T(0), w2 = o2 ? T(2) * C.D[k] : T(0);
-            d1 += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2;
-            d2 += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2;
+            if constexpr (PAIR) { d1s += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2; d2s += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2; }
+            else { d1 += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2; d2 += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2; }
           }
         }
       });
+      if constexpr (PAIR) {
+        d1 += d1s + pair_xchg(d1s); d2 += d2s + pair_xchg(d2s);
+        m_e1 |= pair_xchg(m_e1); m_e2 |= pair_xchg(m_e2); m_e3 |= pair_xchg(m_e3);
+      }
       if constexpr (SELF && S::NSELF > 0) static_for<0, 2 * S::NSELF>([&](auto PP) {
         constexpr int p = PP; constexpr int ba = S::geom_body[S::self_a[p / 2]], bb = S::geom_body[S::self_b[p / 2]];
         const bool act = (R.mask >> p) & 1u;
@@ -816,7 +856,7 @@ extern __device__ unsigned long long g_ktime[24 + 72];
 #endif
 
 // one forward-dynamics evaluation: qacc(q, v, ctrl)  ([3P] mj_forward)
-template <class T, class S>
+template <class T, class S, bool PAIR = false>
 REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
                           const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV],
                           bool warm = false) {
@@ -843,7 +883,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   REX_STAMP(t_3);
   REX_MARK("detect");
   Constraints<T, S> C;
-  detect_constraints<T, S>(q, v, G, sp, K, C);
+  detect_constraints<T, S, PAIR>(q, v, G, sp, K, C);
   REX_PSTAMP(p_3, C.dist[2 * S::NG - 1] + C.lD[S::NB - 1] + T(C.self_possible));
   REX_STAMP(t_4);
   SolveStats st{0, false, 0};
@@ -894,11 +934,19 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   REX_PSTAMP(p_4, a0[0] + T(R.mask));
   if (mode == 3) {
     REX_MARK("fast_rows");
-    slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
-    st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+    if constexpr (PAIR) {   // two lanes per env: each lane its own end of the feet (even slot 2g holds the own end's data)
+      constexpr unsigned FASTP = FAST & 0x55555555u;
+      slot_rows<T, S, FASTP, false, true>(v, G, P, sp, K, C);
+      st = solve_newton<T, S, false, FASTP, false, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+    } else {
+      slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
+      st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+    }
   } else if (mode == 2) {
+    if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);   // the general instantiations run replicated in both lanes of a pair: every slot
     if constexpr (S::NSELF > 0) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max); }
   } else if (mode == 1) {
+    if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
     slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
     st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
   } else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
@@ -919,7 +967,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
 
 // one mj_step: RK4 ([3P] mj_RungeKutta, N=4) or semi-implicit Euler with implicit joint damping
 // ([3P] mj_Euler).  Returns the OR of "solver hit its cap".
-template <class T, class S>
+template <class T, class S, bool PAIR = false>
 REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
                     const LaneParams<T, S>& P, const SolParams<T>& sp, T (&acc)[S::NV], bool warm) {
   // acc: in = qacc of the previous evaluation (solver warm start when `warm`), out = qacc of the last one
@@ -933,7 +981,7 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
     static_for<0, S::NV>([&](auto II) { q0[II] = q[II]; v0[II] = v[II]; dq[II] = T(0); dv[II] = T(0); });
 #pragma unroll 1
     for (int stage = 0; stage < 4; ++stage) {
-      capped |= forward<T, S>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0)).capped;
+      capped |= forward<T, S, PAIR>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0)).capped;
       const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3);   // B = [1/6 1/3 1/3 1/6]
       const T c = stage == 2 ? h : T(0.5) * h;                             // A = [.5; 0 .5; 0 0 1]
       static_for<0, S::NV>([&](auto II) { constexpr int i = II;
@@ -944,7 +992,7 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
     }
   } else {
     T rhs[S::NV];
-    capped |= forward<T, S>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm).capped;
+    capped |= forward<T, S, PAIR>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm).capped;
     // (M + h*diag(damping)) a = qfrc_smooth + qfrc_constraint = M qacc
     sym_matvec<T, S>(M, acc, rhs);
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ; M[j + 2][j + 2] += h * G.damping[j]; });

@@ -66,6 +66,20 @@ template <class T> REX_HD void opaque(T& x) {
 }
 
 
+// ---- two lanes per environment (the PAIR instantiations of the planar step; device only) ------------------------------
+// Lanes 2i and 2i + 1 hold the SAME environment: everything is replicated bit for bit except the work that splits cleanly
+// by capsule END (lane parity = end): the floor tests and, in the feet-only solver, the whole per-slot part of both passes.
+// Partial results are exchanged with DPP quad permutes (lane ^ 1 inside a quad: no LDS, one VALU instruction, usually fused
+// into the consuming add); sums are commutative, so both lanes of a pair hold identical bits afterwards.
+#if defined(__HIP_DEVICE_COMPILE__)
+REX_HD unsigned pair_parity() { return threadIdx.x & 1u; }
+REX_HD float pair_xchg(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
+REX_HD unsigned pair_xchg(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+#else
+inline unsigned pair_parity() { return 0u; }
+template <class T> inline T pair_xchg(T x) { return x; }   // PAIR is never instantiated on the host
+#endif
+
 template <int N>
 struct IC { static constexpr int value = N; constexpr operator int() const { return N; } };
 

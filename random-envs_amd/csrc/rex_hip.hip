@@ -281,7 +281,10 @@ __device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepF
 #endif
 #define REX_STEP_OCC __attribute__((amdgpu_waves_per_eu(REX_STEP_WAVES, REX_STEP_WAVES)))
 
-template <class S>
+// PAIR: two lanes per environment (lane 2i and 2i + 1 both hold env i; planar_spec.hpp "two lanes per environment"):
+// the launch has 2 B lanes in 64-lane blocks = 32 envs per wave, exactly the envs-per-wave of the 32-lane 1-lane-per-env
+// launch, but the wave is full and the per-slot work of the feet-only solver is split over the two lanes.
+template <class S, bool PAIR>
 __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
                                                          SolParams<float> sp, const float* __restrict__ action,
                                                          float* __restrict__ obs, float* __restrict__ reward,
@@ -291,8 +294,8 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
 #if defined(REX_WAVETIME)
   const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
 #endif
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
-  if (i >= s.B) return;
+  const unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);   // 32-bit lane offset + uniform (SGPR) row bases
+  if (i >= s.B) return;   // (both lanes of a pair leave together: i is the same)
   const long long B = s.B;
   float q[S::NV], v[S::NV], ctrl[S::NU], xi[S::NXI];
   static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; q[k] = (s.qpos + (size_t)k * B)[i]; v[k] = (s.qvel + (size_t)k * B)[i]; });
@@ -311,7 +314,8 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
   float acc[S::NV];
   static_for<0, S::NV>([&](auto KK) { acc[KK] = 0.0f; });
 #pragma unroll 1
-  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
+  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S, PAIR>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
+  if (PAIR && (threadIdx.x & 1u)) return;   // the even lane of a pair writes the results and runs the fused reset
 #if defined(REX_KTIME)
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[5], __builtin_amdgcn_s_memtime() - tk0);
 #endif
@@ -613,6 +617,7 @@ struct rex_env {
   float* d_scratch = nullptr;   // MAX_XI floats
   float* d_chol = nullptr;      // MAX_XI*MAX_XI floats (fullgaussian Cholesky factor)
   int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
+  int pair = 1;                 // planar chains: two lanes per env (REX_PAIR=0: one lane per env)
   // timing: event pool created by rex_enable_timing, used as a ring by rex_step (no allocation in the step path)
   int timing = 0;
   std::vector<hipEvent_t> ev0, ev1;
@@ -808,6 +813,8 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_LS_MAX")) h->sp.ls_max = atoi(getenv("REX_LS_MAX"));   // tuning knobs
   if (getenv("REX_WARM")) h->sp.warm = atoi(getenv("REX_WARM"));
   if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
+  if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
+  if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);
@@ -928,6 +935,19 @@ extern "C" int rex_set_random_task(rex_t* h, const uint8_t* mask, void* stream) 
   return do_reset(h, mask, 1, 1, 0, nullptr, (hipStream_t)stream);
 }
 
+template <class S>
+static void launch_planar_step(rex_env* h, const PlanarGeom<float, S>& geom, const float* action, float* obs_out, float* reward_out,
+                               uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out, int fused, int resample, hipStream_t st) {
+  if (h->pair) {   // 2 B lanes in 64-lane blocks: 32 envs per wave
+    const unsigned blocks = (unsigned)((2 * h->B + 63) / 64);
+    hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(64), 0, st, h->dev, h->flags, geom, h->sp, action, obs_out, reward_out,
+                       done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
+  } else {
+    hipLaunchKernelGGL((planar_step_kernel<S, false>), dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, h->dev, h->flags, geom, h->sp, action, obs_out,
+                       reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
+  }
+}
+
 extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
                         uint8_t* truncated_out, float* terminal_obs_out, void* stream) {
   if (!h) return set_err(REX_ERR_ARG, "null handle");
@@ -948,15 +968,15 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
 #endif
 #if REX_EN_HOPPER
     case REX_HOPPER:
-      hipLaunchKernelGGL(planar_step_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->g_hopper, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
+      launch_planar_step<HopperSpec>(h, h->g_hopper, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
 #endif
 #if REX_EN_HALFCHEETAH
     case REX_HALFCHEETAH:
-      hipLaunchKernelGGL(planar_step_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->g_cheetah, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
+      launch_planar_step<HalfCheetahSpec>(h, h->g_cheetah, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
 #endif
 #if REX_EN_WALKER2D
     case REX_WALKER2D:
-      hipLaunchKernelGGL(planar_step_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->g_walker, h->sp, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample_on_reset); break;
+      launch_planar_step<Walker2dSpec>(h, h->g_walker, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
 #endif
 #if REX_EN_HUMANOID
     case REX_HUMANOID:
