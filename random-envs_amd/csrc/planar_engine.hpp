@@ -592,7 +592,7 @@ template <bool BR> REX_HD bool any_lane(bool x) { if constexpr (BR) return REX_W
 template <class T, class S, bool SELF, unsigned SLOTS, bool BR, bool PAIR = false, int MAXIT = 24>
 REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
                                const Kin<T, S>& K, const Constraints<T, S>& C, const SelfRows<T, S>& R,
-                               const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, bool have_a0, int ls_max) {
+                               const LaneParams<T, S>& P, T (&qacc)[S::NV], bool warm, bool have_a0, int ls_max, int ls_free = 0) {
   // MuJoCo starts at qacc_smooth (warmstart is disabled in all the XMLs); the minimiser is unique, so
   // starting from the previous RK4 stage's solution only changes how fast the active set is found
   // (a lane without any row is only here because another lane of its wave has one: it must leave with qacc_smooth)
@@ -815,7 +815,12 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     T a = T(1), lo = T(0), hi = T(-1), d1, d2;
     deriv(a, d1, d2);
     bool ls_done = lane_done || abs_t(d1) <= d1ref;
-    for (int ls = 0; ls < ls_max; ++ls) {   // phi' is piecewise linear and increasing: safeguarded Newton
+    // The first `ls_free` iterations of a solve take the full Newton step without a line search (semismooth Newton: on
+    // this piecewise-quadratic cost it usually finds the active set in as many iterations as with the exact search, and
+    // every evaluation of phi' costs a pass over all rows); from then on the exact search, which guarantees descent,
+    // takes over -- a solve that has not converged by then is a hard one (cycling active sets).
+    const int ls_cap = it < ls_free ? 0 : ls_max;
+    for (int ls = 0; ls < ls_cap; ++ls) {   // phi' is piecewise linear and increasing: safeguarded Newton
       if (!REX_WAVE_ANY(!ls_done)) break;
       if (d1 < T(0)) lo = a; else hi = a;
       T an_ = a - d1 * rcp_t(d2);
@@ -937,18 +942,18 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
     if constexpr (PAIR) {   // two lanes per env: each lane its own end of the feet (even slot 2g holds the own end's data)
       constexpr unsigned FASTP = FAST & 0x55555555u;
       slot_rows<T, S, FASTP, false, true>(v, G, P, sp, K, C);
-      st = solve_newton<T, S, false, FASTP, false, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+      st = solve_newton<T, S, false, FASTP, false, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free);
     } else {
       slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
-      st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+      st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free);
     }
   } else if (mode == 2) {
     if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);   // the general instantiations run replicated in both lanes of a pair: every slot
-    if constexpr (S::NSELF > 0) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max); }
+    if constexpr (S::NSELF > 0) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free); }
   } else if (mode == 1) {
     if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
     slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
-    st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max);
+    st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free);
   } else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
 #if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
   if (mode == 3 && (threadIdx.x & 63) == 0) atomicAdd(&g_kstats[7], 1ull);   // wave-solves on the fast path

@@ -52,6 +52,11 @@ def set_fast(flag):
     lib().ph_set_fast(int(flag))
 
 
+def set_line_search(ls_max=-1, ls_free=-1):
+    """override SolParams.ls_max / ls_free of the following calls (-1: the model's defaults)"""
+    lib().ph_set_ls(int(ls_max), int(ls_free))
+
+
 def last_mode():
     """solver instantiation the last host_forward entered: 0 no rows, 1 general, 2 general + self rows, 3 feet-only"""
     return lib().ph_last_mode()

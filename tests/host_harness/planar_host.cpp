@@ -9,6 +9,8 @@
 using namespace rex;
 
 static int g_fast = 1;   // SolParams::fast of every call below: 1 = allow the feet-only straight-line solver, 0 = general path only
+static int g_ls_max = -1, g_ls_free = -1;   // overrides of SolParams::ls_max / ls_free (-1: the model's defaults)
+extern "C" void ph_set_ls(int ls_max, int ls_free) { g_ls_max = ls_max; g_ls_free = ls_free; }
 static int g_last_mode = -1;   // SolveStats::mode of the last ph_forward
 extern "C" void ph_set_fast(int f) { g_fast = f; }
 extern "C" int ph_last_mode() { return g_last_mode; }
@@ -28,7 +30,7 @@ static void run_step(int n, int nsub, const double* qpos, const double* qvel, co
       T s4[4] = {x[7], x[8], x[9], x[10]};
       derive_model<T, S>(s4, G, nominal, sp);
     }
-    sp.fast = g_fast;
+    sp.fast = g_fast; if (g_ls_max >= 0) sp.ls_max = g_ls_max; if (g_ls_free >= 0) sp.ls_free = g_ls_free;
     LaneParams<T, S> P; lane_params(S{}, x, P);
     bool cap = false; T acc[S::NV];
     for (int k = 0; k < S::NV; k++) acc[k] = T(0);
@@ -49,7 +51,7 @@ static void run_forward(const double* qpos, const double* qvel, const double* ac
   for (int k = 0; k < S::NXI; k++) x[k] = T(xi[k]);
   if (S::KIND == 3) { sz[0] = x[7]; sz[1] = x[8]; sz[2] = x[9]; sz[3] = x[10]; }
   derive_model<T, S>(sz, G, nominal, sp);
-  sp.fast = g_fast;
+  sp.fast = g_fast; if (g_ls_max >= 0) sp.ls_max = g_ls_max; if (g_ls_free >= 0) sp.ls_free = g_ls_free;
   LaneParams<T, S> P; lane_params(S{}, x, P);
   for (int i = 0; i < S::NV; i++) for (int j = 0; j < S::NV; j++) M[i][j] = T(0);
   SolveStats st = forward<T, S>(q, v, c, G, P, sp, a, M);

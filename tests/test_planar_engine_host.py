@@ -4,7 +4,7 @@ reduction itself, fp32 instantiation gives the tolerance the GPU tests use."""
 import numpy as np
 import pytest
 
-from host_harness.build import host_constants, host_forward, host_step, last_mode, set_fast
+from host_harness.build import host_constants, host_forward, host_step, last_mode, set_fast, set_line_search
 from oracle_bindings import (DIMS, oracle_batch_step, oracle_constants, oracle_contacts, oracle_forward,
                              rollout_states)
 from random_envs_amd.specs import SPECS
@@ -125,3 +125,21 @@ def test_fast_and_general_solver_instantiations_agree(kind):
     assert modes[3] > 30, modes
     e32 = np.abs(v32f - v32g).max(1) / (1 + np.abs(v32g).max(1))
     assert np.percentile(e32, 99) < 2e-4 and np.abs(q32f - q32g).max() < 2e-5
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_line_search_schedule_does_not_change_the_solution(kind):
+    """The solver's line-search schedule (SolParams.ls_free full Newton steps, then the safeguarded exact search) only
+    changes HOW the unique minimiser is reached: every schedule gives the oracle's result and none hits the iteration cap."""
+    d = DIMS[kind]
+    q, v, xi = rollout_states(kind, 500, steps_max=70, seed=12)
+    a = np.random.RandomState(6).uniform(-1, 1, (500, d["nu"]))
+    ref = oracle_batch_step(kind, q, v, a, xi)
+    try:
+        for ls_max, ls_free in ((3, 0), (1, 0), (3, 2), (3, 4), (3, 24)):
+            set_line_search(ls_max, ls_free)
+            q64, v64, cap = host_step(kind, False, q, v, a, xi, d["frame_skip"])
+            e = np.abs(v64 - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+            assert e.max() < 1e-6 and cap.sum() == 0, (ls_max, ls_free, e.max(), cap.sum())
+    finally:
+        set_line_search(-1, -1)
