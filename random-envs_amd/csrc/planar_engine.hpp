@@ -60,14 +60,27 @@ struct Kin {
 template <class T>
 REX_HD void rot(T c, T s, T u, T w, T& x, T& z) { x = u * c + w * s; z = -u * s + w * c; }
 
-template <class T, class S>
+template <class T, class S, bool PAIR = false>
 REX_HD void kinematics(const T (&q)[S::NV], const PlanarGeom<T, S>& G, Kin<T, S>& K) {
   T phi[S::NB];
   static_for<0, S::NB>([&](auto I) {
     constexpr int i = I;
     if constexpr (i == 0) phi[0] = q[2];
     else phi[i] = phi[S::parent[i]] + T(S::sgn[i]) * q[i + 2];
-    sincos_t(phi[i], K.s[i], K.c[i]);
+  });
+  if constexpr (PAIR) {   // two lanes per env: each lane evaluates every other body's sin / cos, then they swap
+    const bool odd = pair_parity() != 0u;
+    static_for<0, (S::NB + 1) / 2>([&](auto HH) {
+      constexpr int i0 = 2 * HH, i1 = (2 * HH + 1 < S::NB) ? 2 * HH + 1 : 2 * HH;
+      T so, co; sincos_t(odd ? phi[i1] : phi[i0], so, co);
+      const T sx = pair_xchg(so), cx = pair_xchg(co);
+      K.s[i0] = odd ? sx : so; K.c[i0] = odd ? cx : co;
+      if constexpr (i1 != i0) { K.s[i1] = odd ? so : sx; K.c[i1] = odd ? co : cx; }
+    });
+  }
+  static_for<0, S::NB>([&](auto I) {
+    constexpr int i = I;
+    if constexpr (!PAIR) sincos_t(phi[i], K.s[i], K.c[i]);
     if constexpr (i == 0) { K.A[0][0] = T(0); K.A[0][1] = T(0); }
     else {
       constexpr int p = S::parent[i];
@@ -451,7 +464,22 @@ REX_HD void detect_constraints(const T (&q)[S::NV], const T (&v)[S::NV], const P
   C.lim_mask = lim_mask; C.con_mask = con_mask;
   // bounding-circle cull of the capsule-capsule self pairs
   unsigned sp_any = 0u;
-  if constexpr (S::NSELF > 0) {
+  if constexpr (S::NSELF > 0 && PAIR) {
+    // two lanes per env: the capsule centre is the mean of its two ends, one in each lane (C.px[2g] is the own end's x
+    // relative to the root anchor; the end's z is recovered from the distance to the floor)
+    T ccx[S::NG], ccz[S::NG];
+    static_for<0, S::NG>([&](auto GG) { constexpr int g = GG; constexpr int k = 2 * g;
+      const T ez = C.dist[k] + G.radius[g];   // end-sphere centre z, absolute (the pair difference below cancels the offset)
+      ccx[g] = T(0.5) * (C.px[k] + pair_xchg(C.px[k])); ccz[g] = T(0.5) * (ez + pair_xchg(ez)); });
+    static_for<0, S::NSELF>([&](auto PP) {
+      constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
+      T dx = ccx[gb] - ccx[ga], dz = ccz[gb] - ccz[ga];
+      T la2 = (G.e1[ga][0] - G.e2[ga][0]) * (G.e1[ga][0] - G.e2[ga][0]) + (G.e1[ga][1] - G.e2[ga][1]) * (G.e1[ga][1] - G.e2[ga][1]);
+      T lb2 = (G.e1[gb][0] - G.e2[gb][0]) * (G.e1[gb][0] - G.e2[gb][0]) + (G.e1[gb][1] - G.e2[gb][1]) * (G.e1[gb][1] - G.e2[gb][1]);
+      T reach = T(0.5) * (sqrt_t(la2) + sqrt_t(lb2)) + G.radius[ga] + G.radius[gb] + sp.con_margin;
+      sp_any |= (dx * dx + dz * dz <= reach * reach) ? (1u << p) : 0u;
+    });
+  } else if constexpr (S::NSELF > 0) {
     static_for<0, S::NSELF>([&](auto PP) {
       constexpr int p = PP; constexpr int ga = S::self_a[p], gb = S::self_b[p];
       constexpr int ba = S::geom_body[ga], bb = S::geom_body[gb];
@@ -869,7 +897,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   REX_MARK("kinematics");
   REX_PSTAMP(p_0, q[0]);
   Kin<T, S> K;
-  kinematics<T, S>(q, G, K);
+  kinematics<T, S, PAIR>(q, G, K);
   REX_PSTAMP(p_1, K.c[S::NB - 1] + K.A[S::NB - 1][0] + K.rc[S::NB - 1][1] + K.s[1]);
   REX_STAMP(t_1);
   T f[S::NV], a0[S::NV];
