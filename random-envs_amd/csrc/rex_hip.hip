@@ -682,7 +682,7 @@ static void sp_to_float(const SolParams<double>& a, SolParams<float>& b) {
   b.con_K = (float)a.con_K; b.con_B = (float)a.con_B; b.con_dmin = (float)a.con_dmin; b.con_dmax = (float)a.con_dmax;
   b.con_width = (float)a.con_width; b.con_margin = (float)a.con_margin; b.lim_K = (float)a.lim_K; b.lim_B = (float)a.lim_B;
   b.lim_dmin = (float)a.lim_dmin; b.lim_dmax = (float)a.lim_dmax; b.lim_width = (float)a.lim_width; b.meaninertia = (float)a.meaninertia;
-  b.ls_max = a.ls_max; b.warm = a.warm; b.fast = a.fast; b.ls_free = a.ls_free;
+  b.ls_max = a.ls_max; b.warm = a.warm; b.fast = a.fast; b.ls_free = a.ls_free; b.corr = a.corr;
 }
 
 template <class S>
@@ -813,6 +813,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_LS_MAX")) h->sp.ls_max = atoi(getenv("REX_LS_MAX"));   // tuning knobs
   if (getenv("REX_WARM")) h->sp.warm = atoi(getenv("REX_WARM"));
   if (getenv("REX_LS_FREE")) h->sp.ls_free = atoi(getenv("REX_LS_FREE"));
+  if (getenv("REX_CORR")) h->sp.corr = atoi(getenv("REX_CORR"));
   if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
   if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
   if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
