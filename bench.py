@@ -126,6 +126,9 @@ def main():
                          "(in the air, no contact rows -- cheaper than the steady state where episodes end and restart all the time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: skip the per-launch HIP events")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket every n-th launch of the timed region with HIP events (the two event packets cost ~8 us of stream "
+                         "time per bracketed launch, 9 %% of a hopper step: timing every launch would lower `value` by that much)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the launch path on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--cpu-sample-steps", type=int, default=8)
@@ -186,7 +189,7 @@ def main():
         one_step(k)
     torch.cuda.synchronize()
     t_setup0 = time.perf_counter()
-    env.enable_timing(not args.no_kernel_timing)
+    env.enable_timing(0 if args.no_kernel_timing else max(1, min(args.time_every, max(args.steps // 4, 1))))
     one_step(0)
     torch.cuda.synchronize()
     timing_setup_ms = 1e3 * (time.perf_counter() - t_setup0)
@@ -233,7 +236,7 @@ def main():
                                       "asynchronously every %d steps" % (world, args.scaling, args.counter_every)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": KERNEL_NAME[args.env], "kernel_avg_ms": kavg_ms,
+                         "kernel": KERNEL_NAME[args.env], "kernel_avg_ms": kavg_ms, "kernel_launches_timed": n_k,
                          "algorithmic_bytes_per_launch": bytes_step * B, "bytes_per_env_step": bytes_step,
                          # the same fraction on the WALL clock of the timed region (what `value` is computed from)
                          "achieved_wall": achieved_wall, "frac_wall": achieved_wall / HBM_PEAK_GBS,

@@ -161,10 +161,11 @@ int64_t rex_step_count(const rex_t* h);
  * [2] constraint solves that hit the iteration cap. Copies 4 int64 to `out` [host]; synchronises. */
 int rex_get_counters(rex_t* h, int64_t* out);
 
-/* duration in ms of the rex_step kernel launches since the last enable / read (at most the last 8192), measured
- * with HIP events on the launch stream; returns the number of samples written.  rex_enable_timing(1) creates
+/* duration in ms of the sampled rex_step kernel launches since the last enable / read (at most the last 8192), measured
+ * with HIP events on the launch stream; returns the number of samples written.  The two event packets of a bracketed launch
+ * cost about 8 us of stream time, so throughput runs sample every n-th launch.  rex_enable_timing(1) creates
  * the event pool (the only allocation of the timing path: rex_step itself never allocates). */
-int rex_enable_timing(rex_t* h, int enable);
+int rex_enable_timing(rex_t* h, int every);   /* 0 = off, n >= 1 = bracket every n-th rex_step launch */
 int rex_read_timing(rex_t* h, float* ms_out, int max_n);
 
 const char* rex_last_error(void);

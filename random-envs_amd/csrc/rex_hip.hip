@@ -622,6 +622,7 @@ struct rex_env {
   int timing = 0;
   std::vector<hipEvent_t> ev0, ev1;
   size_t ev_n = 0;              // launches recorded since the last enable / read
+  unsigned long long launches = 0;   // rex_step calls since the last enable (sampling phase)
 };
 constexpr size_t EV_POOL = 8192;
 
@@ -961,8 +962,11 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   // planar envs reset finished lanes inside the step kernel; walker2d with DR needs the separate derive launch
   const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH ||
                                       (h->kind == REX_WALKER2D && !(resample_on_reset && h->dr.type != REX_DR_NONE)))) ? 1 : 0;
-  const size_t ev_slot = h->ev_n % EV_POOL;   // ring over the pool rex_enable_timing created
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
+  // every `timing`-th launch is bracketed by two events of the pool rex_enable_timing created (ring): the two event packets
+  // cost ~8 us of stream time per launch, 9 % of a hopper step, so a throughput run samples (bench.py: every 8th launch)
+  const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;
+  const size_t ev_slot = h->ev_n % EV_POOL;
+  if (timed) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
   switch (h->kind) {
 #if REX_EN_CARTPOLE
     case REX_CARTPOLE:
@@ -985,7 +989,7 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
       hipLaunchKernelGGL(humanoid_step_kernel, g, b, hum_lds_bytes(h), st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
 #endif
   }
-  if (h->timing) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
+  if (timed) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
   HIP_TRY(hipGetLastError());
   h->step_count += h->B;
   if (h->autoreset && !fused) return do_reset(h, h->dev.done, 2, resample_on_reset, 1, obs_out, st);
@@ -1073,7 +1077,7 @@ extern "C" int rex_enable_timing(rex_t* h, int enable) {
       hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
     }
   }
-  h->timing = enable ? 1 : 0; h->ev_n = 0;
+  h->timing = enable > 0 ? enable : 0; h->ev_n = 0; h->launches = 0;
   return REX_OK;
 }
 extern "C" int rex_read_timing(rex_t* h, float* ms_out, int max_n) {

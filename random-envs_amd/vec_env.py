@@ -328,8 +328,9 @@ class VecRandomEnv(DRConfig):
         _native.check(self._L.rex_get_counters(self._h, out))
         return dict(nonfinite=out[0], gaussian_fail=out[1], solver_capped=out[2], overflow=out[3])
 
-    def enable_timing(self, flag=True):
-        _native.check(self._L.rex_enable_timing(self._h, int(flag)))
+    def enable_timing(self, every=1):
+        """HIP-event duration of every `every`-th step kernel launch (True / 1: all of them, 0 / False: off)."""
+        _native.check(self._L.rex_enable_timing(self._h, int(every)))
 
     def read_timing(self, max_n=65536):
         buf = (ctypes.c_float * max_n)()
