@@ -588,7 +588,7 @@ extern __device__ unsigned long long g_evalphase[8192][8];
 
 struct SolveStats { int iters; bool capped; int mode; };   // mode: solver instantiation forward() entered (0 none, 1 general, 2 general + self rows, 3 feet-only straight-line)
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; };
+struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; long toggles[4][4]; };
 inline GlobalStats& gstats() { static GlobalStats g{}; return g; }
 #define REX_COUNT(field, n) (gstats().field += (n))
 #elif defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
@@ -886,6 +886,9 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     if constexpr (!BR && !SELF) {
       const unsigned t_lim = lim_on ^ m_lim, t1 = e1 ^ m_e1, t2 = e2 ^ m_e2, t3 = e3 ^ m_e3, tm = t1 | t2 | t3;
       const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
+#if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+      if (!lane_done && a == T(1)) gstats().toggles[nl < 3 ? nl : 3][ns < 3 ? ns : 3]++;
+#endif
       bool can = !lane_done && a == T(1) && corr != 0 && ((nl == 1 && ns == 0) || (nl == 0 && ns == 1));
       if (REX_WAVE_ANY(can)) {
         T Ut[S::NV], Un[S::NV], Ctt = T(0), Ctn = T(0), Cnn = T(0), wt = T(0), wn = T(0), jt1[NC], jn1[NC];

@@ -84,6 +84,30 @@ def test_step_parity_on_rollout_states(torch_mod, kind, lanes):
     env.close()
 
 
+@pytest.mark.parametrize("knobs", [dict(REX_PAIR=0), dict(REX_CORR=0), dict(REX_FAST=0), dict(REX_PAIR=0, REX_CORR=0, REX_LS_FREE=0, REX_LS_MAX=3)])
+@pytest.mark.parametrize("kind", ["hopper", "walker2d", "halfcheetah"])
+def test_every_solver_configuration_matches_the_oracle(torch_mod, kind, knobs):
+    """The solver's machinery is switchable at create time (REX_PAIR: two lanes per env, REX_CORR: one-group correction,
+    REX_FAST: feet-only instantiation + qacc_smooth skip, REX_LS_FREE / REX_LS_MAX: line-search schedule).  Every
+    configuration reaches the same unique minimiser: each one against the oracle, every lane, same tolerances."""
+    import random_envs_amd as rex
+    from oracle_bindings import DIMS, oracle_batch_step, rollout_states
+    from parity_util import create_knobs
+    n = 1024; d = DIMS[kind]
+    q, v, xi = rollout_states(kind, n, steps_max=60, seed=13)
+    q, v, xi = [x.astype(np.float32).astype(np.float64) for x in (q, v, xi)]
+    a = np.random.RandomState(8).uniform(-1.2, 1.2, (n, d["nu"])).astype(np.float32).astype(np.float64)
+    with create_knobs(**knobs):
+        env = rex.make(IDS[kind], batch=n, autoreset=False)
+    obs, r, dn, qq, vv = _step_from(env, torch_mod, q, v, xi, a)
+    ref = oracle_batch_step(kind, q, v, a, xi)
+    eq = np.abs(qq - ref["qpos"]).max(1); ev = np.abs(vv - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    print(kind, knobs, "max |dqpos| %.2e max |dqvel|rel %.2e" % (eq.max(), ev.max()))
+    assert eq.max() < TOL_QPOS and ev.max() < TOL_QVEL_REL, (kind, knobs, eq.max(), ev.max())
+    assert env.counters()["solver_capped"] == 0
+    env.close()
+
+
 def test_hopper_contact_rich_and_limit_states(torch_mod):
     """random (not rollout) states: deeper penetrations, joint limits violated, large velocities"""
     import random_envs_amd as rex
