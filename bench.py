@@ -171,10 +171,18 @@ def main():
         q0 = q[:1].clone().expand(B, -1).contiguous(); v0 = v[:1].clone().expand(B, -1).contiguous()
         cands = env.sample_tasks(nact).contiguous()        # [nact, B, task_dim] on the device
 
+        fused = env.kind in ("hopper", "halfcheetah")
+        q0z = q0.clone(); q0z[:, 0] = 0                     # get_full_mjstate: root x zeroed
+        q_soa, v_soa = q0z.t().contiguous(), v0.t().contiguous()
+        cands_soa = cands.transpose(1, 2).contiguous()      # [nact, task_dim, B]
+
         def one_step(k):
-            env.set_task(cands[k % nact])                   # device-resident: no host round trip
-            env.set_state(q0, v0)
-            env.step_soa(actions[0])
+            if fused:                                       # ONE launch: caller's SoA (state, xi, action) in, (obs', r, done) out
+                env.replay_soa(q_soa, v_soa, cands_soa[k % nact], actions[0])
+            else:
+                env.set_task(cands[k % nact])               # device-resident: no host round trip
+                env.set_state(q0, v0)
+                env.step_soa(actions[0])
     else:
         def one_step(k):
             env.step_soa(actions[k % nact])
@@ -230,7 +238,7 @@ def main():
             "config": {"workload": "%s%s, batch %d per GPU, uniform DR over the %d-dim xi (nominal +-10%%), "
                                    "U(-%.1f,%.1f) actions, %s" % (args.env, " [replay: 1 logged transition x B candidate xi]" if args.replay else "",
                                                                  B, env.task_dim, amp, amp,
-                                                                 "set_task + set_sim_state + step per call" if args.replay else "auto-reset + xi resample"),
+                                                                 ("one fused rex_replay launch per call" if args.env in ("RandomHopper-v0", "RandomHalfCheetah-v0") else "set_task + set_sim_state + step per call") if args.replay else "auto-reset + xi resample"),
                        "global_batch": total_steps // max(args.steps, 1),
                        "parallelism": "index-sharded envs x%d (%s scaling), no data-path collective; step counter all-reduced "
                                       "asynchronously every %d steps" % (world, args.scaling, args.counter_every)},

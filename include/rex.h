@@ -118,6 +118,14 @@ int rex_reset(rex_t* h, const uint8_t* mask, float* obs_out, void* stream);
 int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
              uint8_t* truncated_out, float* terminal_obs_out, void* stream);
 
+/* Offline replay of logged transitions under candidate xi (get_full_mjstate + set_sim_state + step, random_hopper.py:128-152,
+ * random_half_cheetah.py:136-158): one env.step per lane from the CALLER's qpos [dev, nq*batch], qvel [dev, nv*batch],
+ * xi [dev, task_dim*batch], action [dev, act_dim*batch] into obs_out / reward_out / done_out, in ONE launch; nothing of the
+ * handle is read back or changed (state, task, step / episode counters).  Hopper and half-cheetah, regular ids
+ * (REX_ERR_UNSUPPORTED otherwise: use rex_set_task + rex_set_state + rex_step). */
+int rex_replay(rex_t* h, const float* qpos, const float* qvel, const float* xi, const float* action,
+               float* obs_out, float* reward_out, uint8_t* done_out, void* stream);
+
 /* get_sim_state / set_sim_state (random_hopper.py:148-152), MujocoEnv.set_state
  * (jinja_mujoco_env.py:146-154), state_vector (:231-235). qpos [dev, nq*batch], qvel [dev, nv*batch].
  * CartPole: qpos = (x, theta), qvel = (x_dot, theta_dot). */

@@ -15,7 +15,7 @@ SYMBOLS = [
     "rex_set_autoreset", "rex_seed", "rex_reset", "rex_step", "rex_get_state", "rex_set_state",
     "rex_get_task", "rex_set_task", "rex_set_random_task", "rex_get_obs", "rex_step_count",
     "rex_get_counters", "rex_enable_timing", "rex_read_timing", "rex_last_error", "rex_version",
-    "rex_get_counters_state", "rex_set_counters_state", "rex_sample_task", "rex_set_info_buffer", "rex_export_lane", "rex_get_aux", "rex_set_aux",
+    "rex_get_counters_state", "rex_set_counters_state", "rex_sample_task", "rex_set_info_buffer", "rex_export_lane", "rex_get_aux", "rex_set_aux", "rex_replay",
 ]
 
 ENV_KINDS = {"cartpole": 0, "hopper": 1, "halfcheetah": 2, "walker2d": 3, "humanoid": 4}
@@ -75,6 +75,7 @@ def lib():
     L.rex_sample_task.argtypes = [vp, vp, u64, vp]
     L.rex_set_info_buffer.argtypes = [vp, vp]
     L.rex_export_lane.argtypes = [vp, i64, fp, fp, fp]
+    L.rex_replay.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rex_get_aux.argtypes = [vp, vp, vp]
     L.rex_set_aux.argtypes = [vp, vp, vp]
     L.rex_last_error.restype = ctypes.c_char_p

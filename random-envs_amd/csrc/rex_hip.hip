@@ -177,6 +177,7 @@ struct StepFlags {
   int endless, noisy, time_limit, max_steps;
   float noise_std;
   float* info;   // optional per-term reward rows [n_info][B] (random_half_cheetah.py:110, random_humanoid.py:182-187); null = off
+  int readonly;  // rex_replay: state comes from the caller's buffers and nothing of the handle is written (no t / done / state stores, no reset)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -346,11 +347,14 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
   if (fl.endless) dn = false;            // random_hopper.py:95-96
   if (!finite) atomicAdd(s.counters + 0, 1ull);
   if (capped && threadIdx.x == 0) atomicAdd(s.counters + 2, 1ull);
-  int t = s.t[i] + 1; s.t[i] = t;
-  bool trunc = fl.time_limit && t >= fl.max_steps && !dn;     // gym TimeLimit
+  int t = s.t[i] + 1;
+  bool trunc = fl.time_limit && t >= fl.max_steps && !dn && !fl.readonly;     // gym TimeLimit
   bool d = dn || trunc;
-  static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = q[k]; (s.qvel + (size_t)k * B)[i] = v[k]; });
-  s.done[i] = d ? 2 : 0;
+  if (!fl.readonly) {
+    s.t[i] = t;
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = q[k]; (s.qvel + (size_t)k * B)[i] = v[k]; });
+    s.done[i] = d ? 2 : 0;
+  }
   rocrand_state_philox4x32_10 st;
   if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
                              (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
@@ -737,7 +741,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (h->lanes < 8 || h->lanes > 64 || (h->lanes & (h->lanes - 1))) { int l = h->lanes; delete h; return set_err(REX_ERR_ARG, "REX_LANES must be 8, 16, 32 or 64 (got %d)", l); }
   h->dims = dims;
   h->flags.endless = 0; h->flags.noisy = 0; h->flags.time_limit = 1; h->flags.max_steps = dims.max_episode_steps;
-  h->flags.noise_std = 0.0f; h->flags.info = nullptr;
+  h->flags.noise_std = 0.0f; h->flags.info = nullptr; h->flags.readonly = 0;
   h->full_dim = full.task_dim;
   h->dr.type = REX_DR_NONE; h->dr.dim = dims.task_dim;
   variant_map(env_kind, variant, full.task_dim, h->dr.map);
@@ -993,6 +997,36 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   HIP_TRY(hipGetLastError());
   h->step_count += h->B;
   if (h->autoreset && !fused) return do_reset(h, h->dev.done, 2, resample_on_reset, 1, obs_out, st);
+  return REX_OK;
+}
+
+// Offline replay (random_hopper.py:128-152 get_full_mjstate / set_sim_state + step): one env.step per lane
+// from the CALLER's (qpos, qvel, xi, action) straight into the caller's outputs -- one launch, no copies, and nothing of the
+// handle changes (its state, task, counters and RNG position stay where they were).
+extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const float* xi, const float* action,
+                          float* obs_out, float* reward_out, uint8_t* done_out, void* stream) {
+  if (!h || !qpos || !qvel || !xi || !action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_replay: null argument");
+  if (h->variant || (h->kind != REX_HOPPER && h->kind != REX_HALFCHEETAH))
+    return set_err(REX_ERR_UNSUPPORTED, "rex_replay: hopper / half-cheetah (regular ids) only; use set_task + set_state + step for the others");
+  HIP_TRY(hipSetDevice(h->device));
+  rex_env view = *h;                        // a shallow view of the handle whose state rows are the caller's buffers
+  view.dev.qpos = const_cast<float*>(qpos); view.dev.qvel = const_cast<float*>(qvel); view.dev.xi = const_cast<float*>(xi);
+  view.flags.readonly = 1; view.flags.info = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;   // same sampling as rex_step
+  const size_t ev_slot = h->ev_n % EV_POOL;
+  if (timed) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
+  if (h->kind == REX_HOPPER) {
+#if REX_EN_HOPPER
+    launch_planar_step<HopperSpec>(&view, h->g_hopper, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
+#endif
+  } else {
+#if REX_EN_HALFCHEETAH
+    launch_planar_step<HalfCheetahSpec>(&view, h->g_cheetah, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
+#endif
+  }
+  if (timed) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
+  HIP_TRY(hipGetLastError());
   return REX_OK;
 }
 

@@ -259,6 +259,8 @@ class VecRandomEnv(DRConfig):
         """One logged transition per env under this env's (or the given) xi: set_sim_state(get_full_mjstate(obs)),
         step(action) without auto-reset side effects -> next observation.  The massively parallel inner loop of
         offline system identification (many candidate xi x one transition each)."""
+        if self.kind in ("hopper", "halfcheetah") and not self.unmodeled:
+            return self._replay_fused(obs, action, self.get_task() if xi is None else xi)
         keep = self.autoreset
         self.autoreset = False; self._push_flags()
         try:
@@ -270,6 +272,32 @@ class VecRandomEnv(DRConfig):
             return nxt.clone(), r.clone(), d.clone()
         finally:
             self.autoreset = keep; self._push_flags()
+
+    def replay_soa(self, qpos_soa, qvel_soa, xi_soa, action_soa):
+        """Zero-copy fused replay (hopper, half-cheetah): ONE kernel launch reads the caller's contiguous SoA device tensors
+        -- qpos [nq, batch] (root x zeroed, as get_full_mjstate gives it), qvel [nv, batch], xi [task_dim, batch], action
+        [act_dim, batch] -- and writes next observation / reward / done into buffers of this object (valid until the next
+        replay call); the env itself (state, task, counters, RNG position) is not touched."""
+        t = self._torch
+        if not hasattr(self, "_rp_obs"):
+            self._rp_obs = t.empty(self.dims.obs_dim, self.batch, dtype=t.float32, device=self.device)
+            self._rp_r = t.empty(self.batch, dtype=t.float32, device=self.device)
+            self._rp_d = t.empty(self.batch, dtype=t.uint8, device=self.device)
+        p = lambda z: ctypes.c_void_p(z.data_ptr())
+        _native.check(self._L.rex_replay(self._h, p(qpos_soa), p(qvel_soa), p(xi_soa), p(action_soa), p(self._rp_obs), p(self._rp_r),
+                                         p(self._rp_d), self._stream()))
+        return self._rp_obs, self._rp_r, self._rp_d
+
+    def _replay_fused(self, obs, action, xi):
+        """[batch, dim] convenience form of :meth:`replay_soa`: returns fresh [batch, ...] tensors."""
+        t = self._torch
+        q, v = self.get_full_mjstate(obs)
+        x = t.as_tensor(xi, dtype=t.float32, device=self.device).reshape(self.batch, self.task_dim)
+        a = t.as_tensor(action, dtype=t.float32, device=self.device).reshape(self.batch, self.dims.act_dim)
+        keep = (q.t().contiguous(), v.t().contiguous(), x.t().contiguous(), a.t().contiguous())
+        self._replay_keep = keep              # alive until the launch has consumed them (stream-ordered)
+        o, r, d = self.replay_soa(*keep)
+        return o.t().clone(), r.clone(), d.bool()
 
     def state_vector(self):                   # jinja_mujoco_env.py:231-235
         q, v = self.get_state()

@@ -272,6 +272,35 @@ def test_replay_transitions_every_chain(torch_mod, eid):
     env.close(); env2.close()
 
 
+def test_fused_replay_matches_the_three_call_path_and_leaves_the_env_alone(torch_mod):
+    """rex_replay (hopper, half-cheetah): one launch from the caller's buffers == set_task + set_sim_state + step bit for bit,
+    and the handle's own state, task and counters are untouched."""
+    import random_envs_amd as rex
+    torch = torch_mod
+    for eid in ("RandomHopper-v0", "RandomHalfCheetah-v0"):
+        B = 2048
+        env = rex.make(eid, batch=B, seed=11)
+        nom = torch.tensor(env.original_task)
+        env.set_dr_distribution("uniform", torch.stack([0.8 * nom, 1.2 * nom], 1).flatten().tolist()); env.set_dr_training(True)
+        env.reset()
+        g = torch.Generator().manual_seed(2)
+        for _ in range(12):
+            obs, _, _, _ = env.step(torch.rand(B, env.dims.act_dim, generator=g) * 2 - 1)
+        obs = obs.clone(); a = torch.rand(B, env.dims.act_dim, generator=g) * 2 - 1
+        xi = env.sample_task()
+        before = env.get_full_state()
+        nxt, r, d = env.replay_transitions(obs, a, xi)
+        after = env.get_full_state()
+        for k in before:
+            assert torch.equal(before[k], after[k]), (eid, k)
+        ref_env = rex.make(eid, batch=B, seed=5, autoreset=False)
+        q, v = ref_env.get_full_mjstate(obs)
+        ref_env.set_task(xi); ref_env.set_state(q, v)
+        o2, r2, d2, _ = ref_env.step(a)
+        assert torch.equal(nxt, o2) and torch.equal(r, r2) and torch.equal(d, d2), eid
+        env.close(); ref_env.close()
+
+
 # ------------------------------------------------------------------------------------------------- lane export / adapter
 def test_export_lane_and_sb3_adapter(torch_mod):
     import random_envs_amd as rex
