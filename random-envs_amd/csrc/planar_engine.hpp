@@ -575,10 +575,10 @@ REX_HD void make_self_rows(const T (&v)[S::NV], const PlanarGeom<T, S>& G, const
 #define REX_MARK(name) ((void)0)
 #endif
 
-#if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
+#if (defined(REX_WAVETIME) || defined(REX_PHASES)) && defined(__HIP_DEVICE_COMPILE__)
 // diagnostic build only: cycles per phase of forward(), summed per wave (lane 0) with fire-and-forget atomics.  The stamp
 // takes a value the phase produced as an input, so that value is complete before the clock is read.
-extern __device__ unsigned long long g_evalphase[8192][8];
+extern __device__ unsigned long long g_evalphase[8192][16];
 #define REX_PSTAMP(var, dep) unsigned long long var; { float dep_ = (float)(dep); asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : "v"(dep_) : "memory"); }
 #define REX_PACC(slot, t0, t1) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_evalphase[blockIdx.x & 8191][slot], (t1) - (t0)); } while (0)
 #else
@@ -770,11 +770,15 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
         }
       });
     }
+    REX_PSTAMP(s_h, H[S::NV - 1][0] + H[S::NV - 1][S::NV - 1] + H[2][2]);
+    REX_PACC(7, s_1, s_h);
     REX_MARK("pass2_ldl");
     ldl_factor<T, S>(H);
     T sr[S::NV];
     static_for<0, S::NV>([&](auto II) { sr[II] = -g[II]; });
     ldl_solve<T, S>(H, sr);
+    REX_PSTAMP(s_l, sr[0] + sr[S::NV - 1]);
+    REX_PACC(8, s_h, s_l);
     REX_MARK("pass2_ls");
     // ---- exact line search on phi(alpha); phi'(0) = g.sr, Gauss curvature sr^T M sr ----------
     T Ms[S::NV];
@@ -861,6 +865,8 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       deriv(a, d1, d2);
       ls_done = ls_done || abs_t(d1) <= d1ref || a == prev;
     }
+    REX_PSTAMP(s_d, d1 + d2 + a);
+    REX_PACC(9, s_l, s_d);
     REX_MARK("pass2_update");
     // full Newton step that stays in the region its Hessian was built for: exact minimiser, no
     // verification pass needed (same argument as `same_set` above)
@@ -872,6 +878,8 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     if (it >= 12) printf("     alpha %.6g smax %.3e amax %.3e d1 %.3e d0 %.3e\n", double(a), double(smax), double(amax), double(d1), double(d0));
 #endif
     lane_done = lane_done || exact_step || smax <= stag * (T(1) + amax);   // stagnation at rounding level
+    REX_PSTAMP(s_u, qacc[0] + amax + smax);
+    REX_PACC(10, s_d, s_u);
     // ---- one-group correction (straight-line instantiation) ---------------------------------------------------------
     // x1 = x + sr minimises the quadratic model of the set A its Hessian was built for.  The usual reason a lane needs
     // another iteration is that the set at x1 differs from A in ONE group of rows: one joint limit, or the (up to three)
@@ -956,7 +964,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       }
     }
     REX_PSTAMP(s_2, qacc[0] + amax);
-    REX_PACC(6, s_1, s_2);
+    REX_PACC(6, s_1, s_2); REX_PACC(11, s_u, s_2);
     st.iters = it + 1;
     if (it == MAXIT - 1) st.capped = REX_WAVE_ANY(!lane_done);
   }

@@ -56,10 +56,16 @@ extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build 
 // B = 32 768 is the SLOWEST wave's, not the average)
 namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; __device__ unsigned long long g_wavehum[1024][16];
                 __device__ unsigned long long g_wavephase[8192][4];
-                __device__ unsigned long long g_evalphase[8192][8]; }   // forward(): kinematics, mass+bias, detect, dispatch+self, solve (all), pass 1, pass 2
+                }
+#endif
+#if defined(REX_WAVETIME) || defined(REX_PHASES)
+namespace rex { __device__ unsigned long long g_evalphase[8192][16]; }   // forward(): kinematics, mass+bias, detect, dispatch+self, rows+solve, pass 1, pass 2, H, ldl+solve, phi', update, correction
 extern "C" int rex_debug_evalphase(unsigned long long* out, int n) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_evalphase), sizeof(unsigned long long) * 8 * (n < 8192 ? n : 8192)) != hipSuccess) return -1;
-  static unsigned long long z[8192][8]; return hipMemcpyToSymbol(HIP_SYMBOL(rex::g_evalphase), z, sizeof z) == hipSuccess ? 0 : -1; }   // planar step kernel: cycles entry -> state loaded -> substeps done -> outputs stored -> fused reset done
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_evalphase), sizeof(unsigned long long) * 16 * (n < 8192 ? n : 8192)) != hipSuccess) return -1;
+  static unsigned long long z[8192][16]; return hipMemcpyToSymbol(HIP_SYMBOL(rex::g_evalphase), z, sizeof z) == hipSuccess ? 0 : -1; }
+#endif
+#if defined(REX_WAVETIME)
+// g_wavephase: planar step kernel, cycles entry -> state loaded -> substeps done -> outputs stored -> fused reset done
 extern "C" int rex_debug_wavephase(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavephase), sizeof(unsigned long long) * 4 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1; }
 extern "C" int rex_debug_wavehum(unsigned long long* out) {   // humanoid: per-wave phase accumulators of the last launch (-DREX_KTIME -DREX_WAVETIME)

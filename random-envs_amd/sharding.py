@@ -29,7 +29,8 @@ def shard_strong(global_batch, rank, world):
 def init(backend, device=None):
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    # REX_FORCE_DIST=1: initialise the process group at world size 1 too (exercises the RCCL path on a one-GPU box)
+    if (world > 1 or os.environ.get("REX_FORCE_DIST")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {}

@@ -89,3 +89,19 @@ def test_replay_workload_line():
     assert r["bytes_per_env_step"] == 173 + 4 * 4 and r["traffic"] is None
     assert abs(r["achieved"] - r["bytes_per_env_step"] * 8192 / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert d["nonfinite_lanes"] == 0
+
+
+def test_rccl_path_at_world_size_one():
+    """backend "nccl" (= RCCL) end to end on the one GPU of this box: process group with device_id, the asynchronous
+    all-reduce of the step counter on a device tensor, the MAX of the elapsed time, barrier, shutdown.  (N > 1 over xGMI
+    needs the driver's multi-GPU node.)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, REX_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4",
+                          "--batch", "4096", "--counter-every", "8", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["counter_reductions"] == 4 and d["config"]["global_batch"] == 4096
+    assert abs(d["value"] - 4096 * 24 / (d["ms_per_step"] * 24 / 1e3)) < 1e-6 * d["value"]
