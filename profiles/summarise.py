@@ -6,12 +6,12 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-ks = glob.glob(os.path.join(P, "trace", "*", "*_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(P, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run of this tag
 if ks:
-    shutil.copy(ks[0], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
+    shutil.copy(ks[-1], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
 out = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    for f in glob.glob(os.path.join(P, name, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(P, name, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:   # newest run only
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
