@@ -956,6 +956,9 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
 #else
         const bool ok2 = v_lim == m_lim && v1 == m_e1 && v2 == m_e2 && v3 == m_e3;
 #endif
+#if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+        if (can) { gstats().toggles[3][3]++; if (ok2) gstats().toggles[3][2]++; }   // corrections tried / accepted
+#endif
         lane_done = lane_done || (can && ok2);
         // x2 was computed for the set at x1: that is what the next gradient pass compares with
         p_lim = can ? m_lim : p_lim; p_e1 = can ? m_e1 : p_e1; p_e2 = can ? m_e2 : p_e2; p_e3 = can ? m_e3 : p_e3;

@@ -949,14 +949,15 @@ extern "C" int rex_set_random_task(rex_t* h, const uint8_t* mask, void* stream) 
 }
 
 template <class S>
-static void launch_planar_step(rex_env* h, const PlanarGeom<float, S>& geom, const float* action, float* obs_out, float* reward_out,
-                               uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out, int fused, int resample, hipStream_t st) {
+static void launch_planar_step(rex_env* h, const DevState& dev, const StepFlags& flags, const PlanarGeom<float, S>& geom, const float* action,
+                               float* obs_out, float* reward_out, uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out,
+                               int fused, int resample, hipStream_t st) {
   if (h->pair) {   // 2 B lanes in 64-lane blocks: 32 envs per wave
     const unsigned blocks = (unsigned)((2 * h->B + 63) / 64);
-    hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(64), 0, st, h->dev, h->flags, geom, h->sp, action, obs_out, reward_out,
+    hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(64), 0, st, dev, flags, geom, h->sp, action, obs_out, reward_out,
                        done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
   } else {
-    hipLaunchKernelGGL((planar_step_kernel<S, false>), dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, h->dev, h->flags, geom, h->sp, action, obs_out,
+    hipLaunchKernelGGL((planar_step_kernel<S, false>), dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, flags, geom, h->sp, action, obs_out,
                        reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
   }
 }
@@ -984,15 +985,15 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
 #endif
 #if REX_EN_HOPPER
     case REX_HOPPER:
-      launch_planar_step<HopperSpec>(h, h->g_hopper, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
+      launch_planar_step<HopperSpec>(h, h->dev, h->flags, h->g_hopper, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
 #endif
 #if REX_EN_HALFCHEETAH
     case REX_HALFCHEETAH:
-      launch_planar_step<HalfCheetahSpec>(h, h->g_cheetah, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
+      launch_planar_step<HalfCheetahSpec>(h, h->dev, h->flags, h->g_cheetah, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
 #endif
 #if REX_EN_WALKER2D
     case REX_WALKER2D:
-      launch_planar_step<Walker2dSpec>(h, h->g_walker, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
+      launch_planar_step<Walker2dSpec>(h, h->dev, h->flags, h->g_walker, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
 #endif
 #if REX_EN_HUMANOID
     case REX_HUMANOID:
@@ -1015,20 +1016,20 @@ extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const 
   if (h->variant || (h->kind != REX_HOPPER && h->kind != REX_HALFCHEETAH))
     return set_err(REX_ERR_UNSUPPORTED, "rex_replay: hopper / half-cheetah (regular ids) only; use set_task + set_state + step for the others");
   HIP_TRY(hipSetDevice(h->device));
-  rex_env view = *h;                        // a shallow view of the handle whose state rows are the caller's buffers
-  view.dev.qpos = const_cast<float*>(qpos); view.dev.qvel = const_cast<float*>(qvel); view.dev.xi = const_cast<float*>(xi);
-  view.flags.readonly = 1; view.flags.info = nullptr;
+  DevState dev = h->dev;                    // the handle's device view with the state rows replaced by the caller's buffers
+  dev.qpos = const_cast<float*>(qpos); dev.qvel = const_cast<float*>(qvel); dev.xi = const_cast<float*>(xi);
+  StepFlags flags = h->flags; flags.readonly = 1; flags.info = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;   // same sampling as rex_step
   const size_t ev_slot = h->ev_n % EV_POOL;
   if (timed) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
   if (h->kind == REX_HOPPER) {
 #if REX_EN_HOPPER
-    launch_planar_step<HopperSpec>(&view, h->g_hopper, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
+    launch_planar_step<HopperSpec>(h, dev, flags, h->g_hopper, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
 #endif
   } else {
 #if REX_EN_HALFCHEETAH
-    launch_planar_step<HalfCheetahSpec>(&view, h->g_cheetah, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
+    launch_planar_step<HalfCheetahSpec>(h, dev, flags, h->g_cheetah, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
 #endif
   }
   if (timed) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
