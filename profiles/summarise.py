@@ -45,9 +45,9 @@ try:
 except Exception:
     rec = {}
 for env_id, kname in bench.KERNEL_NAME.items():
-    short = kname.replace("<", "<rex::")
+    short = kname.replace("<", "<rex::").rstrip(">")   # the step kernel carries a second template argument (PAIR)
     for k in out:
-        if (short in k or kname in k) and "hbm_bytes_per_launch" in out[k]:
+        if (short in k or kname.rstrip(">") in k) and "hbm_bytes_per_launch" in out[k]:
             rec[env_id] = {"kernel": k, "bytes_per_launch": out[k]["hbm_bytes_per_launch"]["total_corrected"],
                            "source_digest": bench.source_digest(),
                            "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag}
