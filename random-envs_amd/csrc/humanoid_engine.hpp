@@ -790,6 +790,79 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
   return it;
 }
 
+// The same sweeps for NC <= 16 with A stored SQUARE, row-major with row stride NP = NC rounded up to a multiple of 4, then
+// b[NP] and 1/A_ii[NP] (NP^2 + 2 NP <= 288 words).  A row is NP / 4 contiguous 16-byte LDS reads that land in aligned register
+// pairs -- what v_pk_fma_f32 wants -- instead of NC scattered words of the packed triangle that have to be re-paired with
+// moves: 19 instead of 28 instructions per row update.
+constexpr int sq_stride(int nc) { return (nc + 3) / 4 * 4; }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float pgs_v2f __attribute__((ext_vector_type(2)));
+typedef float pgs_v4f __attribute__((ext_vector_type(4)));
+template <int Q, int N> __device__ __forceinline__ void pin_v4(pgs_v4f (&a)[N]) { if constexpr (Q < N) { asm volatile("" : "+v"(a[Q])); pin_v4<Q + 1>(a); } }
+__device__ __forceinline__ void pin_v2(pgs_v2f& x) { asm volatile("" : "+v"(x)); }
+#endif
+template <int NC, class T>
+REX_HD int pgs_sweeps_sq(const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
+  constexpr int NP = sq_stride(NC), BOFF = NP * NP, DOFF = BOFF + NP;
+  static_assert(DOFF + NP <= DUAL_WORDS && NC <= DUAL_NMAX, "square layout must fit the LDS column");
+  const T scale = T(1) / (m.meaninertia * T(NV));
+  int it = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK)
+  if constexpr (sizeof(T) == 4) {
+    typedef pgs_v2f v2f; typedef pgs_v4f v4f;
+    v2f fp[NP / 2];
+    static_for<0, NP / 2>([&](auto QQ) { fp[QQ] = v2f{0.0f, 0.0f}; });
+    v4f buf[NP / 4]; v2f bd;
+    auto load_row = [&](auto II, v4f (&a)[NP / 4], v2f& x) {
+      constexpr int i = II;
+      static_for<0, NP / 4>([&](auto QQ) { constexpr int q = QQ; a[q] = *(const v4f*)(col + i * NP + 4 * q); });
+      x = v2f{col[BOFF + i], col[DOFF + i]};
+    };
+    load_row(IC<0>{}, buf, bd);
+    for (; it < m.iterations; it++) {
+      float improvement = 0;
+      static_for<0, NC>([&](auto II) {
+        constexpr int i = II, nxt = (i + 1) % NC;
+        v4f a[NP / 4]; v2f x = bd;
+        static_for<0, NP / 4>([&](auto QQ) { a[QQ] = buf[QQ]; });
+        load_row(IC<nxt>{}, buf, bd);   // next row in flight while this one is consumed
+        pin_v4<0>(a); pin_v2(x);
+        v2f acc0 = {x.x, 0.0f}, acc1 = {0.0f, 0.0f};
+        static_for<0, NP / 4>([&](auto QQ) {
+          constexpr int q = QQ;
+          acc0 = __builtin_elementwise_fma(v2f{a[q].x, a[q].y}, fp[2 * q], acc0);
+          acc1 = __builtin_elementwise_fma(v2f{a[q].z, a[q].w}, fp[2 * q + 1], acc1);
+        });
+        const v2f t = acc0 + acc1;
+        const float res = t.x + t.y;
+        const float old = (i & 1) ? fp[i / 2].y : fp[i / 2].x;
+        const float nf = __builtin_fmaxf(0.0f, old - res * x.y), df = nf - old;   // a NaN residual (non-finite state: the lane is flagged) gives 0
+        if constexpr (i & 1) fp[i / 2].y = nf; else fp[i / 2].x = nf;
+        const float aii = a[i / 4][i & 3];
+        improvement -= df * (0.5f * df * aii + res);
+      });
+      if (improvement * scale < m.tolerance) { it++; break; }
+    }
+    static_for<0, NC>([&](auto II) { constexpr int i = II; f[i] = (i & 1) ? fp[i / 2].y : fp[i / 2].x; });
+    return it;
+  } else
+#endif
+  {
+    for (; it < m.iterations; it++) {
+      T improvement = 0;
+      for (int i = 0; i < NC; i++) {
+        T res = col[BOFF + i];
+        for (int j = 0; j < NC; j++) res += col[i * NP + j] * f[j];
+        const T old = f[i], nf = hmax(T(0), old - res * col[DOFF + i]), df = nf - old;
+        f[i] = nf;
+        improvement -= df * (T(0.5) * df * col[i * NP + i] + res);
+      }
+      if (improvement * scale < m.tolerance) { it++; break; }
+    }
+    return it;
+  }
+}
+
 // dot product of two nv-vectors; on the device (fp32) eleven v_pk_fma_f32 + one fma instead of 23 fma
 template <class T>
 REX_HD T dot_nv(const T (&a)[NV], const T (&b)[NV]) {
@@ -818,7 +891,18 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
   const int n = K.nefc;
   T* const col = (T*)__builtin_assume_aligned(&dual(s, 0), 16);
   REX_HSTAMP(p0);
-  static_for<0, DUAL_DI + DUAL_NMAX>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
+  // Sweeps run over the smallest of eight fixed sizes that holds every lane of the wave (the launch ends with its slowest wave
+  // and sweeps cost 50 x NC rows: sizes in steps of two above 8).  Sizes up to 16 keep A square (pgs_sweeps_sq), the two largest
+  // the packed lower triangle; the level is wave-uniform, so the layout is known before A is built.
+  int lvl = 0;
+  static_for<0, 8>([&](auto LL) { constexpr int thr[8] = {4, 8, 10, 12, 14, 16, 18, 21}; if (REX_WAVE_ANY(n > thr[LL])) lvl = LL + 1; });
+#if defined(__HIP_DEVICE_COMPILE__)
+  lvl = __builtin_amdgcn_readfirstlane(lvl);
+#endif
+  const bool sq = lvl <= 5;
+  const int stride = lvl == 0 ? 4 : lvl == 1 ? 8 : lvl <= 3 ? 12 : 16;          // sq_stride of the level's NC
+  const int boff = sq ? stride * stride : DUAL_B, doff = sq ? boff + stride : DUAL_DI;
+  static_for<0, DUAL_WORDS>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
   T jnext[NV + 2];   // row j + 1 (and its R, aref) is fetched from scratch while row j goes through the solve
   for (int k = 0; k < NV; k++) jnext[k] = s.J[0][k];
   jnext[NV] = s.R[0]; jnext[NV + 1] = s.aref[0];
@@ -830,8 +914,9 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
     pin_row<0>(jr);
     solve(F, x);
     const T b = dot_nv(jr, K.qacc_smooth) - arefj;
-    col[DUAL_B + j] = b;
-    T* const pa = col + tri(j);
+    col[boff + j] = b;
+    T* const pa = col + (sq ? j * stride : tri(j));   // row j, columns 0..j
+    T* const pt = col + j;                            // square layout: column j of the earlier rows (the mirror entries)
     for (int i = 0; i < j; i += 3) {   // three earlier rows per trip: all their scratch reads are issued before the first is used
       const int i1 = i + 1 < j ? i + 1 : i, i2 = i + 2 < j ? i + 2 : i;   // (clamped duplicates are computed and dropped)
       T r0[NV], r1[NV], r2[NV];
@@ -839,32 +924,24 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
       pin_row<0>(r0); pin_row<0>(r1); pin_row<0>(r2);
       const T a0 = dot_nv(r0, x), a1 = dot_nv(r1, x), a2 = dot_nv(r2, x);
       pa[i] = a0; if (i + 1 < j) pa[i + 1] = a1; if (i + 2 < j) pa[i + 2] = a2;
+      if (sq) { pt[i * stride] = a0; if (i + 1 < j) pt[(i + 1) * stride] = a1; if (i + 2 < j) pt[(i + 2) * stride] = a2; }
     }
     const T a = Rj + dot_nv(jr, x);
-    pa[j] = a; col[DUAL_DI + j] = rcp_t(a);
+    pa[j] = a; col[doff + j] = rcp_t(a);
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
-  // Sweeps over the smallest of eight fixed sizes that holds every lane of the wave.
   int it;
   T f[DUAL_NMAX];
   static_for<0, DUAL_NMAX>([&](auto II) { f[II] = T(0); });
-  {
-    // the launch ends with its slowest wave and sweeps cost 50 x NC rows: sizes in steps of two above 8
-    int lvl = 0;
-    static_for<0, 8>([&](auto LL) { constexpr int thr[8] = {4, 8, 10, 12, 14, 16, 18, 21}; if (REX_WAVE_ANY(n > thr[LL])) lvl = LL + 1; });
-#if defined(__HIP_DEVICE_COMPILE__)
-    lvl = __builtin_amdgcn_readfirstlane(lvl);
-#endif
-    switch (lvl) {
-      case 0: it = pgs_sweeps<4>(m, col, n, f); break;
-      case 1: it = pgs_sweeps<8>(m, col, n, f); break;
-      case 2: it = pgs_sweeps<10>(m, col, n, f); break;
-      case 3: it = pgs_sweeps<12>(m, col, n, f); break;
-      case 4: it = pgs_sweeps<14>(m, col, n, f); break;
-      case 5: it = pgs_sweeps<16>(m, col, n, f); break;
-      case 6: it = pgs_sweeps<18>(m, col, n, f); break;
-      default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
-    }
+  switch (lvl) {
+    case 0: it = pgs_sweeps_sq<4>(m, col, f); break;
+    case 1: it = pgs_sweeps_sq<8>(m, col, f); break;
+    case 2: it = pgs_sweeps_sq<10>(m, col, f); break;
+    case 3: it = pgs_sweeps_sq<12>(m, col, f); break;
+    case 4: it = pgs_sweeps_sq<14>(m, col, f); break;
+    case 5: it = pgs_sweeps_sq<16>(m, col, f); break;
+    case 6: it = pgs_sweeps<18>(m, col, n, f); break;
+    default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
   }
   REX_HSTAMP(p2); REX_HACC(K, HT_SWEEPS, p1, p2); REX_HCNT(K, HC_SWEEPS, it);
   T x[NV];
@@ -888,7 +965,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
 
 // [3P] mj_forward
 template <class T>
-REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc) {
+REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc, bool keep_obs = true) {
   K.overflow = 0;
   REX_HSTAMP(t0);
   MassFactor<T> F;
@@ -905,9 +982,12 @@ REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* 
     static_for<1, NJNT>([&](auto JJ) { constexpr int j = JJ; K.qfrc_smooth[j + 5] -= m.jnt_stiff[j] * qpos[j + 6]; });   // springref 0
     // M right away: 185 values replace cinert + cdof (278) in the set that has to survive the collision phase
     crb(m, S, F);
-    // observation inputs: stored, not kept
+    // observation inputs: stored, not kept -- and only by the evaluation the observation is taken from (the last of an env
+    // step: 261 words per lane that 19 of 20 evaluations would write for nothing)
+    if (keep_obs) {
     static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) s.obs_cinert[b][k] = S.cinert[b][k]; for (int k = 0; k < 6; k++) s.obs_cvel[b][k] = S.cvel[b][k]; s.obs_xipos_x[b] = S.xipos[b][0]; });
     static_for<0, NV>([&](auto II) { s.obs_qfrc_actuator[II] = act[II]; });
+    }
   }
   REX_FENCE(); REX_HSTAMP(t3); REX_HACC(K, HT_SMOOTH, t0, t3);
   limit_rows(m, qpos, qvel, K, s);
@@ -942,13 +1022,13 @@ REX_HD void integrate_pos(T* qpos, const T* qvel, T h) {
 
 // One mj_step with RK4 ([3P] mj_RungeKutta, N = 4).  The stage accumulators are parked in Scratch while forward() runs.
 template <class T>
-REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s) {
+REX_HD void substep(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, bool last_frame = true) {
   const T h = m.timestep;
   static_for<0, NQ>([&](auto KK) { s.rk_q0[KK] = qpos[KK]; });
   static_for<0, NV>([&](auto KK) { s.rk_v0[KK] = qvel[KK]; s.rk_dq[KK] = 0; s.rk_dv[KK] = 0; });
   for (int stage = 0; stage < 4; stage++) {
     T acc[NV];
-    forward(m, L, qpos, qvel, ctrl, K, s, acc);
+    forward(m, L, qpos, qvel, ctrl, K, s, acc, last_frame && stage == 3);   // mj_step ends with stage 4's forward: what _get_obs reads
     const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3), c = stage == 2 ? h : T(0.5) * h;
     T dq[NV], dv[NV];
     static_for<0, NV>([&](auto KK) { constexpr int k = KK; dq[k] = s.rk_dq[k] + w * qvel[k]; dv[k] = s.rk_dv[k] + w * acc[k]; });
@@ -987,7 +1067,7 @@ REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, cons
   T mt = 0, s0 = 0, s1 = 0, asq = 0;
   for (int b = 0; b < NBODY; b++) { mt += L.mass[b]; s0 += L.mass[b] * xipos_x[b]; }
   for (int u = 0; u < NU; u++) asq += action[u] * action[u];       // data.ctrl holds the raw action (:167)
-  for (int f = 0; f < 5; f++) substep(m, L, qpos, qvel, action, K, s);   // frame_skip 5 (:41)
+  for (int f = 0; f < 5; f++) substep(m, L, qpos, qvel, action, K, s, f == 4);   // frame_skip 5 (:41)
   static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = s.obs_xipos_x[b]; s1 += L.mass[b] * xipos_x[b]; });
   const T dt = m.timestep * T(5);
   reward = T(1.25) * (s1 / mt - s0 / mt) / dt - T(0.1) * asq - T(0) /* cfrc_ext = 0, SURVEY Q15 */ + T(5);
