@@ -793,7 +793,7 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
 // The same sweeps for NC <= 16 with A stored SQUARE, row-major with row stride NP = NC rounded up to a multiple of 4, then
 // b[NP] and 1/A_ii[NP] (NP^2 + 2 NP <= 288 words).  A row is NP / 4 contiguous 16-byte LDS reads that land in aligned register
 // pairs -- what v_pk_fma_f32 wants -- instead of NC scattered words of the packed triangle that have to be re-paired with
-// moves: 19 instead of 28 instructions per row update.
+// moves.
 constexpr int sq_stride(int nc) { return (nc + 3) / 4 * 4; }
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float pgs_v2f __attribute__((ext_vector_type(2)));
@@ -810,40 +810,42 @@ REX_HD int pgs_sweeps_sq(const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK)
   if constexpr (sizeof(T) == 4) {
     typedef pgs_v2f v2f; typedef pgs_v4f v4f;
-    v2f fp[NP / 2];
-    static_for<0, NP / 2>([&](auto QQ) { fp[QQ] = v2f{0.0f, 0.0f}; });
-    v4f buf[NP / 4]; v2f bd;
-    auto load_row = [&](auto II, v4f (&a)[NP / 4], v2f& x) {
+    // Residual form: res_r = b_r + sum_j A_rj f_j is kept current for every row; an update of f_k by df pushes A_rk df into
+    // all of them (column k = row k, A is symmetric).  The same multiply-adds as a row dot product per update, but they are
+    // independent of one another: the dependent chain from one row's update to the next is fma, max, sub, pk_fma instead of
+    // a whole dot product and its reduction -- what counts for a lone wave on its SIMD.
+    v2f rp[NP / 2]; float fv[NC];
+    static_for<0, NP / 4>([&](auto QQ) { constexpr int q = QQ; const v4f b4 = *(const v4f*)(col + BOFF + 4 * q); rp[2 * q] = v2f{b4.x, b4.y}; rp[2 * q + 1] = v2f{b4.z, b4.w}; });
+    static_for<0, NC>([&](auto II) { fv[II] = 0.0f; });
+    v4f buf[NP / 4]; float dnext;
+    auto load_row = [&](auto II, v4f (&a)[NP / 4], float& d) {
       constexpr int i = II;
       static_for<0, NP / 4>([&](auto QQ) { constexpr int q = QQ; a[q] = *(const v4f*)(col + i * NP + 4 * q); });
-      x = v2f{col[BOFF + i], col[DOFF + i]};
+      d = col[DOFF + i];
     };
-    load_row(IC<0>{}, buf, bd);
+    load_row(IC<0>{}, buf, dnext);
     for (; it < m.iterations; it++) {
       float improvement = 0;
       static_for<0, NC>([&](auto II) {
         constexpr int i = II, nxt = (i + 1) % NC;
-        v4f a[NP / 4]; v2f x = bd;
+        v4f a[NP / 4]; const float di = dnext;
         static_for<0, NP / 4>([&](auto QQ) { a[QQ] = buf[QQ]; });
-        load_row(IC<nxt>{}, buf, bd);   // next row in flight while this one is consumed
-        pin_v4<0>(a); pin_v2(x);
-        v2f acc0 = {x.x, 0.0f}, acc1 = {0.0f, 0.0f};
-        static_for<0, NP / 4>([&](auto QQ) {
-          constexpr int q = QQ;
-          acc0 = __builtin_elementwise_fma(v2f{a[q].x, a[q].y}, fp[2 * q], acc0);
-          acc1 = __builtin_elementwise_fma(v2f{a[q].z, a[q].w}, fp[2 * q + 1], acc1);
-        });
-        const v2f t = acc0 + acc1;
-        const float res = t.x + t.y;
-        const float old = (i & 1) ? fp[i / 2].y : fp[i / 2].x;
-        const float nf = __builtin_fmaxf(0.0f, old - res * x.y), df = nf - old;   // a NaN residual (non-finite state: the lane is flagged) gives 0
-        if constexpr (i & 1) fp[i / 2].y = nf; else fp[i / 2].x = nf;
+        load_row(IC<nxt>{}, buf, dnext);   // next row in flight while this one is consumed
+        const float res = (i & 1) ? rp[i / 2].y : rp[i / 2].x;
+        const float old = fv[i], nf = __builtin_fmaxf(0.0f, old - res * di), df = nf - old;   // a NaN residual (non-finite state: the lane is flagged) gives 0
+        fv[i] = nf;
         const float aii = a[i / 4][i & 3];
         improvement -= df * (0.5f * df * aii + res);
+        const v2f dfp = {df, df};
+        static_for<0, NP / 4>([&](auto QQ) {
+          constexpr int q = QQ;
+          rp[2 * q] = __builtin_elementwise_fma(v2f{a[q].x, a[q].y}, dfp, rp[2 * q]);
+          rp[2 * q + 1] = __builtin_elementwise_fma(v2f{a[q].z, a[q].w}, dfp, rp[2 * q + 1]);
+        });
       });
       if (improvement * scale < m.tolerance) { it++; break; }
     }
-    static_for<0, NC>([&](auto II) { constexpr int i = II; f[i] = (i & 1) ? fp[i / 2].y : fp[i / 2].x; });
+    static_for<0, NC>([&](auto II) { f[II] = fv[II]; });
     return it;
   } else
 #endif
@@ -903,31 +905,44 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
   const int stride = lvl == 0 ? 4 : lvl == 1 ? 8 : lvl <= 3 ? 12 : 16;          // sq_stride of the level's NC
   const int boff = sq ? stride * stride : DUAL_B, doff = sq ? boff + stride : DUAL_DI;
   static_for<0, DUAL_WORDS>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
-  T jnext[NV + 2];   // row j + 1 (and its R, aref) is fetched from scratch while row j goes through the solve
+  // Every scratch read of the build is issued well before its first use: row j + 1 (with R, aref) and the first two earlier
+  // rows while row j goes through the solve, then the earlier rows two at a time, one pair ahead of the dot products
+  // (ping-pong buffers) -- a scratch read is an HBM-latency trip, and a lone wave has nothing else to run meanwhile.
+  T jnext[NV + 2];
   for (int k = 0; k < NV; k++) jnext[k] = s.J[0][k];
   jnext[NV] = s.R[0]; jnext[NV + 1] = s.aref[0];
   for (int j = 0; j < n; j++) {
-    T x[NV], jr[NV];
-    for (int k = 0; k < NV; k++) { jr[k] = jnext[k]; x[k] = jr[k]; }
-    const T Rj = jnext[NV], arefj = jnext[NV + 1];
-    { const int jn = j + 1 < n ? j + 1 : j; for (int k = 0; k < NV; k++) jnext[k] = s.J[jn][k]; jnext[NV] = s.R[jn]; jnext[NV + 1] = s.aref[jn]; }
-    pin_row<0>(jr);
-    solve(F, x);
-    const T b = dot_nv(jr, K.qacc_smooth) - arefj;
-    col[boff + j] = b;
+    T x[NV], ra[NV], rb[NV], rc[NV], rd[NV];
     T* const pa = col + (sq ? j * stride : tri(j));   // row j, columns 0..j
     T* const pt = col + j;                            // square layout: column j of the earlier rows (the mirror entries)
-    for (int i = 0; i < j; i += 3) {   // three earlier rows per trip: all their scratch reads are issued before the first is used
-      const int i1 = i + 1 < j ? i + 1 : i, i2 = i + 2 < j ? i + 2 : i;   // (clamped duplicates are computed and dropped)
-      T r0[NV], r1[NV], r2[NV];
-      for (int k = 0; k < NV; k++) { r0[k] = s.J[i][k]; r1[k] = s.J[i1][k]; r2[k] = s.J[i2][k]; }
-      pin_row<0>(r0); pin_row<0>(r1); pin_row<0>(r2);
-      const T a0 = dot_nv(r0, x), a1 = dot_nv(r1, x), a2 = dot_nv(r2, x);
-      pa[i] = a0; if (i + 1 < j) pa[i + 1] = a1; if (i + 2 < j) pa[i + 2] = a2;
-      if (sq) { pt[i * stride] = a0; if (i + 1 < j) pt[(i + 1) * stride] = a1; if (i + 2 < j) pt[(i + 2) * stride] = a2; }
+    auto fetch2 = [&](int i, T (&u)[NV], T (&v)[NV]) {   // rows i, i + 1 clamped below j (duplicates are computed and dropped)
+      const int i0 = i < j ? i : 0, i1 = i + 1 < j ? i + 1 : i0;
+      for (int k = 0; k < NV; k++) { u[k] = s.J[i0][k]; v[k] = s.J[i1][k]; }
+    };
+    auto use2 = [&](int i, T (&u)[NV], T (&v)[NV]) {
+      pin_row<0>(u); pin_row<0>(v);
+      const T a0 = dot_nv(u, x), a1 = dot_nv(v, x);
+      if (i < j) { pa[i] = a0; if (sq) pt[i * stride] = a0; }
+      if (i + 1 < j) { pa[i + 1] = a1; if (sq) pt[(i + 1) * stride] = a1; }
+    };
+    {
+      T jr[NV];
+      for (int k = 0; k < NV; k++) { jr[k] = jnext[k]; x[k] = jr[k]; }
+      const T Rj = jnext[NV], arefj = jnext[NV + 1];
+      { const int jn = j + 1 < n ? j + 1 : j; for (int k = 0; k < NV; k++) jnext[k] = s.J[jn][k]; jnext[NV] = s.R[jn]; jnext[NV + 1] = s.aref[jn]; }
+      fetch2(0, ra, rb);
+      pin_row<0>(jr);
+      solve(F, x);
+      col[boff + j] = dot_nv(jr, K.qacc_smooth) - arefj;
+      const T a = Rj + dot_nv(jr, x);
+      pa[j] = a; col[doff + j] = rcp_t(a);
     }
-    const T a = Rj + dot_nv(jr, x);
-    pa[j] = a; col[doff + j] = rcp_t(a);
+    for (int i = 0; i < j; i += 4) {
+      fetch2(i + 2, rc, rd);
+      use2(i, ra, rb);
+      fetch2(i + 4, ra, rb);
+      use2(i + 2, rc, rd);
+    }
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
   int it;
