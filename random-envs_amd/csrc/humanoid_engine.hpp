@@ -630,23 +630,32 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
   static_assert((kPairs.n + 31) / 32 == 4, "pair mask words");
   T* const col = &dual(s, 0);
   int nq = 0;
+  // the lane's next candidate (table order) and its pair record: the record is gathered from the constant table one
+  // candidate AHEAD, so that its latency (a vector load per lane, L2 at best) runs behind the current pair's narrow phase
+  auto pop = [&]() -> int {
+    if ((w0 | w1 | w2 | w3) == 0u) return -1;
+    const unsigned wsel = w0 ? w0 : (w1 ? w1 : (w2 ? w2 : w3));
+    const int base = w0 ? 0 : (w1 ? 32 : (w2 ? 64 : 96));
+    const unsigned cleared = wsel & (wsel - 1u);
+    if (w0) w0 = cleared; else if (w1) w1 = cleared; else if (w2) w2 = cleared; else w3 = cleared;
+    return base + __builtin_ctz(wsel);
+  };
+  int p = pop();
+  PairRec<T> pr = m.pair[p < 0 ? 0 : p];
   bool more = true;
   while (more) {
     for (;;) {   // gather: lanes with candidates left and room for two more hits
-      const bool go = ((w0 | w1 | w2 | w3) != 0u) && nq <= HITQ_MAX - 2;
+      const bool go = p >= 0 && nq <= HITQ_MAX - 2;
       if (!REX_WAVE_ANY(go)) break;
       REX_HSTAMP(n0);
       if (go) {
-        const unsigned wsel = w0 ? w0 : (w1 ? w1 : (w2 ? w2 : w3));
-        const int base = w0 ? 0 : (w1 ? 32 : (w2 ? 64 : 96));
-        const int p = base + __builtin_ctz(wsel);
-        const unsigned cleared = wsel & (wsel - 1u);
-        if (w0) w0 = cleared; else if (w1) w1 = cleared; else if (w2) w2 = cleared; else w3 = cleared;
-        const PairRec<T> pr = m.pair[p];   // per-lane gather from the constant table
+        const int pn = pop();
+        const PairRec<T> nx = m.pair[pn < 0 ? 0 : pn];
         Hits<T> h; T yaxis[3]; bool has_y;
         collide_pair(m, s, pr, h, yaxis, has_y);
         if (h.n > 0) { T* q = col + HITQ_BASE + HITQ_WORDS * nq; q[0] = h.dist[0]; for (int k = 0; k < 3; k++) { q[1 + k] = h.pos[0][k]; q[4 + k] = h.normal[0][k]; } q[7] = T(p); nq++; }
         if (h.n > 1) { T* q = col + HITQ_BASE + HITQ_WORDS * nq; q[0] = h.dist[1]; for (int k = 0; k < 3; k++) { q[1 + k] = h.pos[1][k]; q[4 + k] = h.normal[1][k]; } q[7] = T(p); nq++; }
+        p = pn; pr = nx;
       }
       REX_HSTAMP(n1); REX_HACC(K, HT_PAIR, n0, n1); REX_HCNT(K, HC_PAIR_CALLS, 1);
     }
@@ -669,7 +678,7 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
       REX_HSTAMP(r1); REX_HACC(K, HT_ROWS, r0, r1); REX_HCNT(K, HC_ROW_CALLS, 1);
     }
     nq = 0;
-    more = REX_WAVE_ANY((w0 | w1 | w2 | w3) != 0u);
+    more = REX_WAVE_ANY(p >= 0);
   }
   REX_HSTAMP(c2); REX_HACC(K, HT_NARROW_LOOP, c1, c2);
 }
