@@ -30,10 +30,10 @@ for eid in sys.argv[1:] or ["RandomHopper-v0"]:
               "sum of means %.0f, slowest wave %.0f; kernel %.4f ms" % (P[:, 0].mean(), P[:, 0].max(), P[:, 1].mean(), P[:, 1].max(), P[:, 2].mean(), P[:, 2].max(),
                                                                      P[:, 3].mean(), P[:, 3].max(), P.sum(1).mean(), P.sum(1).max(), ms))
     if hasattr(_native.lib(), "rex_debug_evalphase") and "Humanoid" not in eid:
-        ep = (ctypes.c_ulonglong * (1024 * 8))(); _native.lib().rex_debug_evalphase(ep, 1024)
+        ep = (ctypes.c_ulonglong * (1024 * 16))(); _native.lib().rex_debug_evalphase(ep, 1024)   # 16 slots per wave
         for k in range(10): env.step_soa(acts[k % 8])
         torch.cuda.synchronize(); _native.lib().rex_debug_evalphase(ep, 1024)
-        E = np.array(list(ep), dtype=np.float64).reshape(1024, 8).mean(0) / 10
+        E = np.array(list(ep), dtype=np.float64).reshape(1024, 16).mean(0) / 10
         nm = ["kinematics", "mass+bias+forces", "detect", "self / a0 / dispatch", "rows + solve", "  pass 1 (all)", "  pass 2 (all)"]
         print("   cycles per wave-step by phase of forward() (16 evaluations): " + " | ".join("%s %.0f" % (nm[k], E[k]) for k in range(7)) + " | sum of 0..4 %.0f" % E[:5].sum())
     print(eid, "cycles per wave-step: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f  -> max/mean %.2f" %
