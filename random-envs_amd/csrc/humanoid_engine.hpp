@@ -65,6 +65,12 @@ constexpr int kBodyDofAdr[NBODY] = {0, 0, 6, 8, 9, 12, 0, 13, 16, 0, 17, 19, 20,
 constexpr int kBodyDofNum[NBODY] = {0, 6, 2, 1, 3, 1, 0, 3, 1, 0, 2, 1, 2, 1};
 constexpr int kGeomBody[NGEOM] = {0, 1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 13};
 constexpr int kGeomType[NGEOM] = {0, 3, 2, 3, 3, 3, 3, 3, 2, 3, 3, 2, 3, 3, 2, 3, 3, 2};   // G_PLANE 0, G_SPHERE 2, G_CAPSULE 3
+// Upper bounds (rounded up in the 6th decimal) of the geoms' radii and capsule half-lengths, humanoid.xml:33-88: literals in
+// the broad phase's second test, which only has to be conservative.  check_topology() holds them against the compiled model.
+constexpr float kGeomRadUB[NGEOM] = {0.f, .070001f, .090001f, .060001f, .060001f, .090001f, .060001f, .049001f, .075001f, .060001f, .049001f, .075001f,
+                                     .040001f, .031001f, .040001f, .040001f, .031001f, .040001f};
+constexpr float kGeomHalfUB[NGEOM] = {0.f, .070001f, 0.f, .060001f, .060001f, .070001f, .170075f, .150001f, 0.f, .170075f, .150001f, 0.f,
+                                      .138566f, .138566f, 0.f, .138566f, .138566f, 0.f};
 // candidate geom pairs in MuJoCo's order ([3P] mj_collision): body pairs ascending, geoms of body 1 x geoms of body 2,
 // no pair inside one weld group (the feet have no joint: they belong to the shins) or between parent and child groups
 struct PairTable { int n; int g1[MAXPAIR], g2[MAXPAIR]; };
@@ -134,6 +140,10 @@ struct Model {
 template <class T> REX_HD T hsqrt(T a);
 template <> REX_HD float hsqrt<float>(float a) { return sqrtf(a); }
 template <> REX_HD double hsqrt<double>(double a) { return sqrt(a); }
+template <class T> REX_HD T fast_sqrt(T a) { return hsqrt(a); }   // where a bound, not a result, is computed
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> REX_HD float fast_sqrt<float>(float a) { return __builtin_amdgcn_sqrtf(a); }   // one v_sqrt_f32 (1 ulp), no denormal fix-up
+#endif
 template <class T> REX_HD T habs(T a) { return a < T(0) ? -a : a; }
 template <class T> REX_HD T hmax(T a, T b) { return a > b ? a : b; }
 template <class T> REX_HD T hmin(T a, T b) { return a < b ? a : b; }
@@ -611,13 +621,37 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
   // ~500-cycle round trips per evaluation were measured).  Opaque copies of the margin and the 17 bounds keep them two adds and a multiply at the use.
   T margin = m.margin, bnd[NGEOM]; opaque(margin);
   static_for<1, NGEOM>([&](auto GG) { constexpr int g = GG; bnd[g] = m.geom_bound[g]; opaque(bnd[g]); });
+  // Second test, fused with the first: bounding spheres of two long capsules side by side (the thighs, the shins: candidates
+  // in 85-100 % of all states, in contact in 0.2-1 %) always overlap.  A lower bound of the segment-segment distance that needs
+  // no closest points: seen along axis 1 (an orthogonal projection never lengthens a distance) segment 1 is a point and
+  // segment 2 has half-length l2 sin(theta), so dist >= |d_perp1| - l2 sin(theta); the same along axis 2.  A pair is dropped
+  // only if a bound exceeds r1 + r2 + margin by 0.1 mm (rounding is 1e-7 here; sizes enter as compile-time upper bounds), so
+  // no contact the narrow phase would report is lost -- it removes 5.5 of 6.5 candidates per state and takes the busiest lane
+  // of a wave from ~19 narrow-phase trips to ~6.
+  T ga[NGEOM][3];
+  static_for<1, NGEOM>([&](auto GG) { constexpr int g = GG;
+    if constexpr (kGeomType[g] == G_CAPSULE) for (int k = 0; k < 3; k++) ga[g][k] = dual(s, GEO_GEOM + (g - 1) * 6 + 3 + k); });
+  const T slack = margin + T(1e-4);
   static_for<0, kPairs.n>([&](auto PP) {
-    constexpr int p = PP, g1 = kPairs.g1[p], g2 = kPairs.g2[p];
+    constexpr int p = PP, g1 = kPairs.g1[p], g2 = kPairs.g2[p], t1 = kGeomType[g1], t2 = kGeomType[g2];
     bool keep;
-    if constexpr (kGeomType[g1] == G_PLANE) keep = !(gp[g2][2] - bnd[g2] > margin);   // bounding sphere above the floor
-    else {
-      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = bnd[g1] + bnd[g2] + margin;
-      keep = !(dot3(d, d) > reach * reach);
+    if constexpr (t1 == G_PLANE) {
+      if constexpr (t2 == G_CAPSULE) keep = !(gp[g2][2] - T(kGeomHalfUB[g2]) * habs(ga[g2][2]) - T(kGeomRadUB[g2]) > slack);   // lowest point of the capsule: what the narrow phase tests
+      else keep = !(gp[g2][2] - bnd[g2] > margin);   // sphere above the floor
+    } else {
+      const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = bnd[g1] + bnd[g2] + margin, dd = dot3(d, d);
+      T worst = dd - reach * reach;   // > 0: bounding spheres apart
+      if constexpr (t1 == G_CAPSULE && t2 == G_CAPSULE) {
+        const T rs = T(kGeomRadUB[g1] + kGeomRadUB[g2]) + slack;
+        const T c = dot3(ga[g1], ga[g2]), sn = fast_sqrt(hmax(T(0), T(1) - c * c)), p1 = dot3(d, ga[g1]), p2 = dot3(d, ga[g2]);
+        const T e1 = rs + T(kGeomHalfUB[g2]) * sn, e2 = rs + T(kGeomHalfUB[g1]) * sn;
+        worst = hmax(worst, hmax((dd - p1 * p1) - e1 * e1, (dd - p2 * p2) - e2 * e2));
+      } else if constexpr (t1 == G_CAPSULE || t2 == G_CAPSULE) {   // a sphere and a capsule: distance of the centre from the capsule's axis line
+        constexpr int gc = t1 == G_CAPSULE ? g1 : g2;
+        const T rs = T(kGeomRadUB[g1] + kGeomRadUB[g2]) + slack, pc = dot3(d, ga[gc]);
+        worst = hmax(worst, (dd - pc * pc) - rs * rs);
+      }
+      keep = !(worst > T(0));
     }
     cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;
   });

@@ -215,6 +215,9 @@ inline bool check_topology(const Model<double>& m) {
   }
   for (int j = 1; j < NJNT; j++) ok = ok && m.jnt_dadr[j] == j + 5 && m.jnt_qadr[j] == j + 6;
   for (int g = 0; g < NGEOM; g++) ok = ok && m.geom_body[g] == kGeomBody[g] && m.geom_type[g] == kGeomType[g];
+  for (int g = 1; g < NGEOM; g++)   // the broad phase's literal size bounds: never below the model's sizes, and tight
+    ok = ok && double(kGeomRadUB[g]) >= m.geom_rad[g] && double(kGeomRadUB[g]) - m.geom_rad[g] < 1e-5
+            && double(kGeomHalfUB[g]) >= m.geom_half[g] && double(kGeomHalfUB[g]) - m.geom_half[g] < 1e-5;
   ok = ok && m.npair == kPairs.n;
   for (int p = 0; p < kPairs.n && p < m.npair; p++) ok = ok && m.pair_g1[p] == kPairs.g1[p] && m.pair_g2[p] == kPairs.g2[p];
   for (int u = 0; u < NU; u++) ok = ok && m.act_dof[u] == kActDof[u];
