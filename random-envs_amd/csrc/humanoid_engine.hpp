@@ -440,45 +440,61 @@ REX_HD T impedance3(const Model<T>& m, T x_abs) {   // power 2, midpoint .5
 }
 
 // Translational Jacobian of a world point p, body-2 chain minus body-1 chain (dof masks), projected on NDIR directions
-// at once: out[d][i] = dir_d . (sign_i * axis_i x (p - anchor_i)).  One pass over the 23 dofs with compile-time indices;
-// dofs no lane of the wave needs are skipped.
+// at once: out[d][i] = dir_d . (sign_i * axis_i x (p - anchor_i)), compile-time dof indices.
 template <int NDIR, class T>
 REX_HD void jac_dirs(Scratch<T>& s, int mask1, int mask2, const T* p, const T* dirs, T (&out)[NDIR][NV]) {
-  static_for<0, NV>([&](auto II) {
+  const int diff = mask1 ^ mask2;   // dofs that move exactly one of the two bodies
+  static_for<0, 3>([&](auto II) {   // root translations: unit columns
     constexpr int i = II;
-    const int in2 = (mask2 >> i) & 1, in1 = (mask1 >> i) & 1;
-    const T sign = T(in2 - in1);
-    for (int d = 0; d < NDIR; d++) out[d][i] = 0;
-    if (REX_WAVE_ANY(in2 != in1)) {
-      T col[3];
-      if constexpr (i < 3) { for (int k = 0; k < 3; k++) col[k] = (k == i) ? T(1) : T(0); }
-      else {
-        T r[3], ax[3];
-        for (int k = 0; k < 3; k++) { r[k] = p[k] - dual(s, GEO_DOF + i * 6 + k); ax[k] = dual(s, GEO_DOF + i * 6 + 3 + k); }
-        cross3(col, ax, r);
-      }
-      for (int d = 0; d < NDIR; d++) out[d][i] = sign * dot3(dirs + 3 * d, col);
-    }
+    const T sign = T(((mask2 >> i) & 1) - ((mask1 >> i) & 1));
+    for (int d = 0; d < NDIR; d++) out[d][i] = sign * dirs[3 * d + i];
   });
+  // The hinge dofs by limb (root rotations, abdomen, the legs, the arms): a limb no lane of the wave needs is skipped, and a
+  // limb that is needed reads all its anchors / axes in ONE batch of LDS reads before the first cross product (a skip test
+  // and a read-wait-compute round trip per dof was 20 serialised LDS latencies per contact).
+  auto limb = [&](auto LO, auto HI) {
+    constexpr int lo = LO, hi = HI, n = hi - lo;
+    for (int d = 0; d < NDIR; d++) for (int i = lo; i < hi; i++) out[d][i] = 0;
+    if (REX_WAVE_ANY((diff & (((1 << n) - 1) << lo)) != 0)) {
+      T an[n][3], ax[n][3];
+      static_for<0, n>([&](auto JJ) { constexpr int j = JJ, i = lo + j; for (int k = 0; k < 3; k++) { an[j][k] = dual(s, GEO_DOF + i * 6 + k); ax[j][k] = dual(s, GEO_DOF + i * 6 + 3 + k); } });
+      static_for<0, n>([&](auto JJ) {
+        constexpr int j = JJ, i = lo + j;
+        const T sign = T(((mask2 >> i) & 1) - ((mask1 >> i) & 1));
+        T r[3] = {p[0] - an[j][0], p[1] - an[j][1], p[2] - an[j][2]}, col[3];
+        cross3(col, ax[j], r);
+        for (int d = 0; d < NDIR; d++) out[d][i] = sign * dot3(dirs + 3 * d, col);
+      });
+    }
+  };
+  limb(IC<3>{}, IC<6>{}); limb(IC<6>{}, IC<9>{}); limb(IC<9>{}, IC<13>{}); limb(IC<13>{}, IC<17>{}); limb(IC<17>{}, IC<20>{}); limb(IC<20>{}, IC<23>{});
 }
 
 // hinge-limit rows ([3P] mj_instantiateLimit; every hinge of the humanoid is limited, humanoid.xml:4).  They precede the
 // contact rows in MuJoCo's row order.
 template <class T>
 REX_HD void limit_rows(const Model<T>& m, const T* qpos, const T* qvel, Kin<T>& K, Scratch<T>& s) {
+  // Both sides of every hinge are tested in one straight-line pass (a joint cannot be beyond both limits); the 17 branches
+  // below then work on registers.  Tested inside the branches, every joint angle -- spilled by then -- came back from scratch
+  // with a wait of its own: 34 serialised memory round trips per evaluation.  (Computing impedance, R and aref up front as
+  // well keeps too much alive across the branches and is slower.)
+  T dist[NJNT], vel[NJNT], jsign[NJNT];
+  static_for<1, NJNT>([&](auto JJ) {
+    constexpr int j = JJ, d = j + 5;
+    const T val = qpos[j + 6], dlo = val - m.jnt_lo[j], dhi = m.jnt_hi[j] - val;   // side -1: dist = val - lo; side +1: dist = hi - val
+    const bool low = dlo < T(0);
+    dist[j] = low ? dlo : dhi; jsign[j] = low ? T(1) : T(-1);                      // J_row = -side e_d
+    vel[j] = jsign[j] * qvel[d];
+  });
   int ne = 0;
   static_for<1, NJNT>([&](auto JJ) {
     constexpr int j = JJ, d = j + 5;
-    const T val = qpos[j + 6];
-    for (int side = -1; side <= 1; side += 2) {
-      T dist = side * ((side < 0 ? m.jnt_lo[j] : m.jnt_hi[j]) - val);
-      if (dist < T(0) && ne < MAXEFC) {
-        for (int k = 0; k < NV; k++) s.J[ne][k] = (k == d) ? T(-side) : T(0);
-        T imp = impedance3(m, habs(dist));
-        s.R[ne] = hmax(T(1e-15), (T(1) - imp) * m.dof_invw[d] * rcp_t(imp));
-        s.aref[ne] = -m.B * (T(-side) * qvel[d]) - m.K * imp * dist;
-        ne++;
-      }
+    if (dist[j] < T(0) && ne < MAXEFC) {
+      for (int k = 0; k < NV; k++) s.J[ne][k] = (k == d) ? jsign[j] : T(0);
+      T imp = impedance3(m, habs(dist[j]));
+      s.R[ne] = hmax(T(1e-15), (T(1) - imp) * m.dof_invw[d] * rcp_t(imp));
+      s.aref[ne] = -m.B * vel[j] - m.K * imp * dist[j];
+      ne++;
     }
   });
   K.nefc = ne;
