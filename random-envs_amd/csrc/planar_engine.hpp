@@ -365,8 +365,12 @@ REX_HD void capsule_capsule_2d(const T (&p1)[2], const T (&a1)[2], T l1, T r1, c
     T ux = T(1), uz = T(0);
     if (len >= T(1e-15)) { const T il = rcp_t(len); ux = dx * il; uz = dz * il; }
     T px_ = c1x + ux * (r1 + d * T(0.5)), pz_ = c1z + uz * (r1 + d * T(0.5));
-    if (!H.h0) { H.h0 = true; H.d0 = d; H.nx0 = ux; H.nz0 = uz; H.cx0 = px_; H.cz0 = pz_; }
-    else if (!H.h1) { H.h1 = true; H.d1 = d; H.nx1 = ux; H.nz1 = uz; H.cx1 = px_; H.cz1 = pz_; }
+    // value selects, not `if (!H.h0) H.d0 = d; else H.d1 = d;`: LLVM sinks the two stores into one store through a selected
+    // ADDRESS, which puts H into scratch (a store + a load with its own wait per field and evaluation)
+    const bool first = !H.h0, second = H.h0 && !H.h1;
+    H.d0 = first ? d : H.d0; H.nx0 = first ? ux : H.nx0; H.nz0 = first ? uz : H.nz0; H.cx0 = first ? px_ : H.cx0; H.cz0 = first ? pz_ : H.cz0;
+    H.d1 = second ? d : H.d1; H.nx1 = second ? ux : H.nx1; H.nz1 = second ? uz : H.nz1; H.cx1 = second ? px_ : H.cx1; H.cz1 = second ? pz_ : H.cz1;
+    H.h1 = H.h1 || second; H.h0 = true;
   };
   T difx = p1[0] - p2[0], difz = p1[1] - p2[1];
   T ma = a1[0] * a1[0] + a1[1] * a1[1], mb = -(a1[0] * a2[0] + a1[1] * a2[1]), mc = a2[0] * a2[0] + a2[1] * a2[1];
