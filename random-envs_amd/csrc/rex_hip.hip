@@ -323,6 +323,9 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
 #pragma unroll 1
   for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S, PAIR>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
   if (PAIR && (threadIdx.x & 1u)) return;   // the even lane of a pair writes the results and runs the fused reset
+  // the output addresses are formed from an opaque copy of the lane index: formed from `i`, the compiler computes all of them
+  // next to the loads at the top, carries them through the solver, spills them and reloads each with a wait of its own
+  unsigned io = i; asm volatile("" : "+v"(io));
 #if defined(REX_KTIME)
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[5], __builtin_amdgcn_s_memtime() - tk0);
 #endif
@@ -353,28 +356,28 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
   if (fl.endless) dn = false;            // random_hopper.py:95-96
   if (!finite) atomicAdd(s.counters + 0, 1ull);
   if (capped && threadIdx.x == 0) atomicAdd(s.counters + 2, 1ull);
-  int t = s.t[i] + 1;
+  int t = s.t[io] + 1;
   bool trunc = fl.time_limit && t >= fl.max_steps && !dn && !fl.readonly;     // gym TimeLimit
   bool d = dn || trunc;
   if (!fl.readonly) {
-    s.t[i] = t;
-    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = q[k]; (s.qvel + (size_t)k * B)[i] = v[k]; });
-    s.done[i] = d ? 2 : 0;
+    s.t[io] = t;
+    static_for<0, S::NV>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[io] = q[k]; (s.qvel + (size_t)k * B)[io] = v[k]; });
+    s.done[io] = d ? 2 : 0;
   }
   rocrand_state_philox4x32_10 st;
-  if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + i),
-                             (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
-  write_obs<S>(q, v, obs, B, i, fl.noisy != 0, fl.noise_std, &st);
-  if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; (term_obs + (size_t)k * B)[i] = (obs + (size_t)k * B)[i]; });
-  reward[i] = r; done_out[i] = d ? 1 : 0;
-  if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
-  if (fl.info) { fl.info[i] = dx / dt; (fl.info + (size_t)B)[i] = -S::CTRL_COST * asq; }   // info: reward_run, reward_ctrl (random_half_cheetah.py:105-110)
+  if (fl.noisy) rocrand_init(s.seed, (unsigned long long)(s.env_offset + io),
+                             (unsigned long long)s.episode[io] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
+  write_obs<S>(q, v, obs, B, io, fl.noisy != 0, fl.noise_std, &st);
+  if (term_obs) static_for<0, S::NOBS>([&](auto KK) { constexpr int k = KK; (term_obs + (size_t)k * B)[io] = (obs + (size_t)k * B)[io]; });
+  reward[io] = r; done_out[io] = d ? 1 : 0;
+  if (trunc_out) trunc_out[io] = trunc ? 1 : 0;
+  if (fl.info) { fl.info[io] = dx / dt; (fl.info + (size_t)B)[io] = -S::CTRL_COST * asq; }   // info: reward_run, reward_ctrl (random_half_cheetah.py:105-110)
   // auto-reset fused into the step launch: finished lanes restart here (saves the masked reset launch and
   // the kernel boundary, ~10 % of a hopper step at B = 32768)
 #if defined(REX_WAVETIME)
   const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-  if (fused_reset && d) planar_reset_lane<S>(s, fl, dr, resample, 1, i, obs);
+  if (fused_reset && d) planar_reset_lane<S>(s, fl, dr, resample, 1, io, obs);
 #if defined(REX_WAVETIME)
   if ((threadIdx.x & 63) == 0) { g_waveinfo[blockIdx.x & 8191][1] += __builtin_amdgcn_s_memtime() - tr0; }   // slot 1 ("iters", unused): cycles in the fused reset
   if ((threadIdx.x & 63) == 0) { unsigned long long* ph = g_wavephase[blockIdx.x & 8191]; ph[0] = tk0 - tp0; ph[1] = tk1 - tk0; ph[2] = tr0 - tk1; ph[3] = __builtin_amdgcn_s_memtime() - tr0; }
