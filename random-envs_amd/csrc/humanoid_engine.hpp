@@ -652,11 +652,15 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
     constexpr int p = PP, g1 = kPairs.g1[p], g2 = kPairs.g2[p], t1 = kGeomType[g1], t2 = kGeomType[g2];
     bool keep;
     if constexpr (t1 == G_PLANE) {
+#if !defined(REX_NO_SECOND_CULL)   // (tests build the harness both ways: the second test must never change a result)
       if constexpr (t2 == G_CAPSULE) keep = !(gp[g2][2] - T(kGeomHalfUB[g2]) * habs(ga[g2][2]) - T(kGeomRadUB[g2]) > slack);   // lowest point of the capsule: what the narrow phase tests
-      else keep = !(gp[g2][2] - bnd[g2] > margin);   // sphere above the floor
+      else
+#endif
+      keep = !(gp[g2][2] - bnd[g2] > margin);   // bounding sphere above the floor
     } else {
       const T d[3] = {gp[g2][0] - gp[g1][0], gp[g2][1] - gp[g1][1], gp[g2][2] - gp[g1][2]}, reach = bnd[g1] + bnd[g2] + margin, dd = dot3(d, d);
       T worst = dd - reach * reach;   // > 0: bounding spheres apart
+#if !defined(REX_NO_SECOND_CULL)
       if constexpr (t1 == G_CAPSULE && t2 == G_CAPSULE) {
         const T rs = T(kGeomRadUB[g1] + kGeomRadUB[g2]) + slack;
         const T c = dot3(ga[g1], ga[g2]), sn = fast_sqrt(hmax(T(0), T(1) - c * c)), p1 = dot3(d, ga[g1]), p2 = dot3(d, ga[g2]);
@@ -667,6 +671,7 @@ REX_HD void collide(const Model<T>& m, const T* qvel, Kin<T>& K, Scratch<T>& s) 
         const T rs = T(kGeomRadUB[g1] + kGeomRadUB[g2]) + slack, pc = dot3(d, ga[gc]);
         worst = hmax(worst, (dd - pc * pc) - rs * rs);
       }
+#endif
       keep = !(worst > T(0));
     }
     cand[p >> 5] |= keep ? (1u << (p & 31)) : 0u;

@@ -122,3 +122,30 @@ def test_env_step_obs_reward(hh):
         assert np.array_equal(d.astype(bool), ref["done"])
     # the obs layout: 22 + 23 + 140 + 84 + 23 + 84 (random_humanoid.py:207-216); cfrc_ext block is zero
     assert ref["obs"].shape[1] == 376 and np.all(ref["obs"][:, 292:] == 0) and np.all(ref["obs"][:, 45:55] == 0)
+
+
+def test_second_broad_phase_test_never_changes_a_result(hh):
+    """The projected segment-distance bounds of the broad phase (humanoid_engine.hpp::collide) only ever drop pairs the
+    narrow phase would find apart: a harness built without them (-DREX_NO_SECOND_CULL) gives the same contacts, the same
+    rows and bit-identical accelerations -- standing, crouched, lying and crumpled bodies, random orientations."""
+    so2 = SO.replace(".so", "_nocull.so")
+    if not os.path.exists(so2) or any(os.path.getmtime(d) > os.path.getmtime(so2) for d in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DREX_NO_SECOND_CULL", "-o", so2, SRC])
+    ref = ctypes.CDLL(so2)
+    rng = np.random.RandomState(11)
+    n = 3000
+    q, v, a, xi = _states(n, 12, spread=0.3)
+    # a third crouched / contorted (joint angles far out), a third low and tilted arbitrarily (lying, crumpled)
+    q[n // 3:, 7:] = rng.uniform(-1.6, 1.6, (n - n // 3, 17))
+    quat = rng.normal(size=(n - 2 * (n // 3), 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    q[2 * (n // 3):, 3:7] = quat; q[2 * (n // 3):, 2] = rng.uniform(0.05, 0.6, n - 2 * (n // 3))
+    ncon = 0
+    for f32 in (0, 1):
+        for i in range(n):
+            qa1 = np.zeros(23); qa2 = np.zeros(23); M = np.zeros(23 * 23); i1 = np.zeros(4, dtype=np.int32); i2 = np.zeros(4, dtype=np.int32)
+            hh.hh_forward(f32, _p(q[i]), _p(v[i]), _p(a[i]), _p(xi[i]), _p(qa1), _p(M), i1.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+            ref.hh_forward(f32, _p(q[i]), _p(v[i]), _p(a[i]), _p(xi[i]), _p(qa2), _p(M), i2.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+            assert (i1[:2] == i2[:2]).all(), (i, i1, i2)
+            assert np.array_equal(qa1, qa2), i
+            ncon += int(i1[0])
+    assert ncon > 4 * n      # the sample is contact-rich (capsule-capsule pairs included)
