@@ -414,11 +414,27 @@ REX_HD void factor(MassFactor<T>& F) {
     F.a[midx(k, k)] = inv;
   });
 }
+// M^-1 = L^-1 D^-1 L^-T in three passes ([3P] mj_solveM); the halves are used on their own by the dual build ([3P] mj_solveM2)
+template <class T>
+REX_HD void solve_back(const MassFactor<T>& F, T (&x)[NV]) {   // x <- L^-T x
+  static_rfor<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II; x[i] -= F.a[midx(k, i)] * x[k]; }); });
+}
+// four right-hand sides at once: every factor entry is fetched once for four multiply-adds (most of the factor sits in
+// AGPRs while the rows occupy the VGPRs: an entry costs a move per use)
+template <class T>
+REX_HD void solve_back4(const MassFactor<T>& F, T (&x0)[NV], T (&x1)[NV], T (&x2)[NV], T (&x3)[NV]) {
+  static_rfor<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II;
+    const T l = F.a[midx(k, i)]; x0[i] -= l * x0[k]; x1[i] -= l * x1[k]; x2[i] -= l * x2[k]; x3[i] -= l * x3[k]; }); });
+}
+template <class T>
+REX_HD void solve_fwd(const MassFactor<T>& F, T (&x)[NV]) {    // x <- L^-1 x
+  static_for<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II; x[k] -= F.a[midx(k, i)] * x[i]; }); });
+}
 template <class T>
 REX_HD void solve(const MassFactor<T>& F, T (&x)[NV]) {
-  static_rfor<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II; x[i] -= F.a[midx(k, i)] * x[k]; }); });
+  solve_back(F, x);
   static_for<0, NV>([&](auto KK) { constexpr int k = KK; x[k] *= F.a[midx(k, k)]; });
-  static_for<0, NV>([&](auto KK) { constexpr int k = KK; for_anc<k>([&](auto II) { constexpr int i = II; x[k] -= F.a[midx(k, i)] * x[i]; }); });
+  solve_fwd(F, x);
 }
 
 // ---- collision ([3P] engine_collision_primitive) -----------------------------------------------------
@@ -969,43 +985,54 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
   const int stride = lvl == 0 ? 4 : lvl == 1 ? 8 : lvl <= 3 ? 12 : 16;          // sq_stride of the level's NC
   const int boff = sq ? stride * stride : DUAL_B, doff = sq ? boff + stride : DUAL_DI;
   static_for<0, DUAL_WORDS>([&](auto KK) { col[KK] = T(0); });   // padding rows / columns must read as zero
-  // Every scratch read of the build is issued well before its first use: row j + 1 (with R, aref) and the first two earlier
-  // rows while row j goes through the solve, then the earlier rows two at a time, one pair ahead of the dot products
-  // (ping-pong buffers) -- a scratch read is an HBM-latency trip, and a lone wave has nothing else to run meanwhile.
-  T jnext[NV + 2];
-  for (int k = 0; k < NV; k++) jnext[k] = s.J[0][k];
-  jnext[NV] = s.R[0]; jnext[NV + 1] = s.aref[0];
-  for (int j = 0; j < n; j++) {
-    T x[NV], ra[NV], rb[NV], rc[NV], rd[NV];
-    T* const pa = col + (sq ? j * stride : tri(j));   // row j, columns 0..j
-    T* const pt = col + j;                            // square layout: column j of the earlier rows (the mirror entries)
-    auto fetch2 = [&](int i, T (&u)[NV], T (&v)[NV]) {   // rows i, i + 1 clamped below j (duplicates are computed and dropped)
-      const int i0 = i < j ? i : 0, i1 = i + 1 < j ? i + 1 : i0;
+  // A = J M^-1 J^T = Y D^-1 Y^T with Y^T = L^-T J^T ([3P] mj_solveM2): only the backward half of the solve per row, four rows
+  // per trip (one pass over the factor for all four).  Row j of the scratch array is overwritten with z_j = D^-1 y_j: the
+  // dots with later rows and the final M^-1 J^T f = L^-1 sum_j f_j z_j need nothing else (J_j is dead once b_j is formed).
+  // Every earlier row is read once per group of four, two rows per read batch, a batch ahead of its dot products.
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    T y0[NV], y1[NV], y2[NV], y3[NV], Rr[4];
+    bool ok[4]; int jj[4];
+    static_for<0, 4>([&](auto TT) { constexpr int t = TT; ok[t] = j0 + t < n; jj[t] = ok[t] ? j0 + t : j0; });   // rows past the lane's count duplicate the group's first row and are dropped
+    { T ar[4];
+      for (int k = 0; k < NV; k++) { y0[k] = s.J[jj[0]][k]; y1[k] = s.J[jj[1]][k]; y2[k] = s.J[jj[2]][k]; y3[k] = s.J[jj[3]][k]; }
+      static_for<0, 4>([&](auto TT) { constexpr int t = TT; Rr[t] = s.R[jj[t]]; ar[t] = s.aref[jj[t]]; });
+      pin_row<0>(y0); pin_row<0>(y1); pin_row<0>(y2); pin_row<0>(y3);
+      const T b0 = dot_nv(y0, K.qacc_smooth) - ar[0], b1 = dot_nv(y1, K.qacc_smooth) - ar[1], b2 = dot_nv(y2, K.qacc_smooth) - ar[2], b3 = dot_nv(y3, K.qacc_smooth) - ar[3];
+      col[boff + j0] = b0; if (ok[1]) col[boff + j0 + 1] = b1; if (ok[2]) col[boff + j0 + 2] = b2; if (ok[3]) col[boff + j0 + 3] = b3; }
+    solve_back4(F, y0, y1, y2, y3);
+    auto rowp = [&](int r) -> T* { return col + (sq ? r * stride : tri(r)); };   // row r of A, columns 0..r
+    auto put = [&](int r, int c, T v) { rowp(r)[c] = v; if (sq && c != r) col[c * stride + r] = v; };   // (r, c) with c <= r, and its mirror in the square layout
+    // entries inside the group: z_u = D^-1 y_u is formed, stored (row j0 + u of the scratch array) and dotted with y_t, t >= u
+    auto within = [&](auto UU, T (&yu)[NV]) {
+      constexpr int u = UU;
+      T z[NV];
+      static_for<0, NV>([&](auto KK) { constexpr int k = KK; z[k] = yu[k] * F.a[midx(k, k)]; });
+      if (ok[u]) {
+        for (int k = 0; k < NV; k++) s.J[j0 + u][k] = z[k];
+        const T d = Rr[u] + dot_nv(z, yu);
+        rowp(j0 + u)[j0 + u] = d; col[doff + j0 + u] = rcp_t(d);
+      }
+      if constexpr (u < 1) { const T v = dot_nv(z, y1); if (ok[1]) put(j0 + 1, j0 + u, v); }
+      if constexpr (u < 2) { const T v = dot_nv(z, y2); if (ok[2]) put(j0 + 2, j0 + u, v); }
+      if constexpr (u < 3) { const T v = dot_nv(z, y3); if (ok[3]) put(j0 + 3, j0 + u, v); }
+    };
+    within(IC<0>{}, y0); within(IC<1>{}, y1); within(IC<2>{}, y2); within(IC<3>{}, y3);
+    // earlier rows (already z rows): two per batch, the next batch in flight while this one is dotted with the four y
+    T ra[NV], rb[NV], rc[NV], rd[NV];
+    auto fetch2 = [&](int i, T (&u)[NV], T (&v)[NV]) {
+      const int i0 = i < j0 ? i : 0, i1 = i + 1 < j0 ? i + 1 : i0;
       for (int k = 0; k < NV; k++) { u[k] = s.J[i0][k]; v[k] = s.J[i1][k]; }
     };
-    auto use2 = [&](int i, T (&u)[NV], T (&v)[NV]) {
-      pin_row<0>(u); pin_row<0>(v);
-      const T a0 = dot_nv(u, x), a1 = dot_nv(v, x);
-      if (i < j) { pa[i] = a0; if (sq) pt[i * stride] = a0; }
-      if (i + 1 < j) { pa[i + 1] = a1; if (sq) pt[(i + 1) * stride] = a1; }
+    auto use1 = [&](int i, T (&u)[NV]) {
+      const T a0 = dot_nv(u, y0), a1 = dot_nv(u, y1), a2 = dot_nv(u, y2), a3 = dot_nv(u, y3);
+      if (i < j0) { put(j0, i, a0); if (ok[1]) put(j0 + 1, i, a1); if (ok[2]) put(j0 + 2, i, a2); if (ok[3]) put(j0 + 3, i, a3); }
     };
-    {
-      T jr[NV];
-      for (int k = 0; k < NV; k++) { jr[k] = jnext[k]; x[k] = jr[k]; }
-      const T Rj = jnext[NV], arefj = jnext[NV + 1];
-      { const int jn = j + 1 < n ? j + 1 : j; for (int k = 0; k < NV; k++) jnext[k] = s.J[jn][k]; jnext[NV] = s.R[jn]; jnext[NV + 1] = s.aref[jn]; }
-      fetch2(0, ra, rb);
-      pin_row<0>(jr);
-      solve(F, x);
-      col[boff + j] = dot_nv(jr, K.qacc_smooth) - arefj;
-      const T a = Rj + dot_nv(jr, x);
-      pa[j] = a; col[doff + j] = rcp_t(a);
-    }
-    for (int i = 0; i < j; i += 4) {
+    fetch2(0, ra, rb);
+    for (int i = 0; i < j0; i += 4) {
       fetch2(i + 2, rc, rd);
-      use2(i, ra, rb);
+      pin_row<0>(ra); pin_row<0>(rb); use1(i, ra); use1(i + 1, rb);
       fetch2(i + 4, ra, rb);
-      use2(i + 2, rc, rd);
+      pin_row<0>(rc); pin_row<0>(rd); use1(i + 2, rc); use1(i + 3, rd);
     }
   }
   REX_HSTAMP(p1); REX_HACC(K, HT_BUILD_A, p0, p1);
@@ -1025,7 +1052,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
   REX_HSTAMP(p2); REX_HACC(K, HT_SWEEPS, p1, p2); REX_HCNT(K, HC_SWEEPS, it);
   T x[NV];
   for (int k = 0; k < NV; k++) x[k] = 0;
-  static_for<0, DUAL_NMAX / 3>([&](auto CC) {   // J^T f, three rows per trip (reads batched; rows >= n re-read row 0 with f = 0)
+  static_for<0, DUAL_NMAX / 3>([&](auto CC) {   // sum_j f_j z_j, three rows per trip (reads batched; rows >= n re-read row 0 with f = 0)
     constexpr int i0 = 3 * CC;
     if (REX_WAVE_ANY(i0 < n)) {
       T r[3][NV], fi[3];
@@ -1036,7 +1063,7 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
       for (int k = 0; k < NV; k++) x[k] += r[0][k] * fi[0] + r[1][k] * fi[1] + r[2][k] * fi[2];
     }
   });
-  solve(F, x);
+  solve_fwd(F, x);
   for (int k = 0; k < NV; k++) qacc[k] = K.qacc_smooth[k] + x[k];
   REX_HSTAMP(p3); REX_HACC(K, HT_QACC, p2, p3);
   return it;
