@@ -571,18 +571,28 @@ REX_HD void sphere_sphere(Hits<T>& h, const Model<T>& m, const T* c1, T r1, cons
   if (dist > m.margin || h.n >= 2) return;
   T n[3] = {1, 0, 0};
   if (len >= T(1e-15)) { const T il = rcp_t(len); n[0] = d[0] * il; n[1] = d[1] * il; n[2] = d[2] * il; }
+  // value selects into both slots, not `if (first) h.pos[0] = .. else h.pos[1] = ..`: LLVM sinks the two stores into one
+  // store through a selected ADDRESS, which puts the whole Hits record into scratch -- every hit then went out and came back
+  // through memory, one wait per field, before it reached the LDS queue
   const bool first = h.n == 0; h.n++;
-  for (int x = 0; x < 3; x++) { const T px = c1[x] + n[x] * (r1 + T(0.5) * dist); if (first) { h.pos[0][x] = px; h.normal[0][x] = n[x]; } else { h.pos[1][x] = px; h.normal[1][x] = n[x]; } }
-  if (first) h.dist[0] = dist; else h.dist[1] = dist;
+  for (int x = 0; x < 3; x++) {
+    const T px = c1[x] + n[x] * (r1 + T(0.5) * dist);
+    h.pos[0][x] = first ? px : h.pos[0][x]; h.normal[0][x] = first ? n[x] : h.normal[0][x];
+    h.pos[1][x] = first ? h.pos[1][x] : px; h.normal[1][x] = first ? h.normal[1][x] : n[x];
+  }
+  h.dist[0] = first ? dist : h.dist[0]; h.dist[1] = first ? h.dist[1] : dist;
 }
 template <class T>
 REX_HD void plane_sphere(Hits<T>& h, const Model<T>& m, const T* c, T r) {
   T dist = c[2] - r;                     // the floor: z = 0, normal +z (humanoid.xml:28)
   if (dist > m.margin || h.n >= 2) return;
   const bool first = h.n == 0; h.n++;
-  const T pz = c[2] - (r + T(0.5) * dist);
-  if (first) { h.dist[0] = dist; h.pos[0][0] = c[0]; h.pos[0][1] = c[1]; h.pos[0][2] = pz; h.normal[0][0] = 0; h.normal[0][1] = 0; h.normal[0][2] = 1; }
-  else { h.dist[1] = dist; h.pos[1][0] = c[0]; h.pos[1][1] = c[1]; h.pos[1][2] = pz; h.normal[1][0] = 0; h.normal[1][1] = 0; h.normal[1][2] = 1; }
+  const T pz = c[2] - (r + T(0.5) * dist), pp[3] = {c[0], c[1], pz}, nn[3] = {T(0), T(0), T(1)};
+  for (int x = 0; x < 3; x++) {   // (value selects: see sphere_sphere)
+    h.pos[0][x] = first ? pp[x] : h.pos[0][x]; h.normal[0][x] = first ? nn[x] : h.normal[0][x];
+    h.pos[1][x] = first ? h.pos[1][x] : pp[x]; h.normal[1][x] = first ? h.normal[1][x] : nn[x];
+  }
+  h.dist[0] = first ? dist : h.dist[0]; h.dist[1] = first ? h.dist[1] : dist;
 }
 
 // narrow phase of one candidate pair ([3P] engine_collision_primitive); yaxis = frame hint of the contacts (capsule axis for
@@ -591,6 +601,7 @@ template <class T>
 REX_HD void collide_pair(const Model<T>& m, Scratch<T>& s, const PairRec<T>& pr, Hits<T>& h, T (&yaxis)[3], bool& has_y) {
   const int t1 = pr.t1, t2 = pr.t2;
   h.n = 0; has_y = false;
+  for (int k = 0; k < 2; k++) { h.dist[k] = 0; for (int x = 0; x < 3; x++) { h.pos[k][x] = 0; h.normal[k][x] = 0; } }
   T p1[3], a1[3], p2[3], a2[3];
   for (int k = 0; k < 3; k++) { p2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + k); a2[k] = dual(s, GEO_GEOM + (pr.g2 - 1) * 6 + 3 + k); yaxis[k] = a2[k]; }
   const T r2 = pr.r2, l2 = pr.l2;
