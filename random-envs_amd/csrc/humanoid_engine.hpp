@@ -780,15 +780,25 @@ REX_HD int solve_pgs(const Model<T>& m, const MassFactor<T>& F, const Kin<T>& K,
   }
   const T scale = T(1) / (m.meaninertia * T(NV));
   int it = 0;
+  const int n = K.nefc;
+  // the rows live in scratch: row i + 1 (J, M^-1 J^T and its four scalars) is fetched while row i is updated -- unpipelined, every
+  // row update was two dependent memory round trips, which is all this path (lying, crumpled bodies: 22 .. 108 rows) waits for
+  T jn[NV], mn[NV], sn[4];
+  auto fetch = [&](int i) { for (int k = 0; k < NV; k++) { jn[k] = s.J[i][k]; mn[k] = s.MiJ[i][k]; } sn[0] = s.R[i]; sn[1] = s.aref[i]; sn[2] = s.Adiag[i]; sn[3] = s.force[i]; };
   for (; it < m.iterations; it++) {
     T improvement = 0;
-    for (int i = 0; i < K.nefc; i++) {
-      T res = s.R[i] * s.force[i] - s.aref[i];
-      for (int k = 0; k < NV; k++) res += s.J[i][k] * qacc[k];
-      T old = s.force[i], nf = hmax(T(0), old - res / s.Adiag[i]), df = nf - old;
+    fetch(0);
+    for (int i = 0; i < n; i++) {
+      T jr[NV], mr[NV];
+      for (int k = 0; k < NV; k++) { jr[k] = jn[k]; mr[k] = mn[k]; }
+      const T Ri = sn[0], arefi = sn[1], Ad = sn[2], old = sn[3];
+      fetch(i + 1 < n ? i + 1 : i);   // (the force of row i + 1 is not written by row i)
+      T res = Ri * old - arefi;
+      for (int k = 0; k < NV; k++) res += jr[k] * qacc[k];
+      const T nf = hmax(T(0), old - res / Ad), df = nf - old;
       s.force[i] = nf;
-      if (df != T(0)) for (int k = 0; k < NV; k++) qacc[k] += s.MiJ[i][k] * df;
-      improvement -= T(0.5) * df * df * s.Adiag[i] + df * res;
+      if (df != T(0)) for (int k = 0; k < NV; k++) qacc[k] += mr[k] * df;
+      improvement -= T(0.5) * df * df * Ad + df * res;
     }
     if (improvement * scale < m.tolerance) { it++; break; }
   }
