@@ -1092,7 +1092,16 @@ REX_HD int solve_pgs_dual(const Model<T>& m, const MassFactor<T>& F, Kin<T>& K, 
 
 // [3P] mj_forward
 template <class T>
-REX_HD int forward(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc, bool keep_obs = true) {
+REX_HD int forward(const Model<T>& m_in, const Lane<T>& L, const T* qpos, const T* qvel, const T* ctrl, Kin<T>& K, Scratch<T>& s, T* qacc, bool keep_obs = true) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_HOIST_MODEL)
+  // The model's ~500 constants are read through an opaque (zero) index every evaluation: read through a loop-invariant address
+  // LICM hoists every scalar load to the kernel's entry, where the SGPRs cannot hold them -- they end up in VGPR lanes and
+  // come back one v_readlane at a time (1 400 of the smooth phase's 7 000 instructions).
+  int zidx = 0; asm volatile("" : "+s"(zidx));
+  const Model<T>& m = (&m_in)[zidx];
+#else
+  const Model<T>& m = m_in;
+#endif
   K.overflow = 0;
   REX_HSTAMP(t0);
   MassFactor<T> F;
