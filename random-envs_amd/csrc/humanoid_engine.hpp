@@ -1106,9 +1106,17 @@ REX_HD int forward(const Model<T>& m_in, const Lane<T>& L, const T* qpos, const 
   REX_HSTAMP(t0);
   MassFactor<T> F;
   {
+    // Order: kinematics (geometry into the LDS column) -> limit rows -> collision -> the rest of the smooth dynamics -> M.
+    // Only the body frames (xmat, xipos: 168 values) are alive across the collision phase this way; with the whole smooth
+    // phase first it was cinert + cdof (278) -- the compiler had sunk crb() behind the collision phase anyway -- or M (185).
     Smooth<T> S;
     kinematics(m, qpos, S, s);
-    com_pos(m, L, S, s);
+    REX_FENCE(); REX_HSTAMP(t3); REX_HACC(K, HT_SMOOTH, t0, t3);
+    limit_rows(m, qpos, qvel, K, s);
+    REX_HSTAMP(t3b); REX_HACC(K, HT_LIMITS, t3, t3b);
+    collide(m, qvel, K, s);
+    REX_FENCE();
+    com_pos(m, L, S, s);   // (reads the joint anchors / axes kinematics left in the LDS column: before the dual overwrites it)
     T qfrc_bias[NV], act[NV];
     com_vel_rne(m, L, qvel, S, qfrc_bias);
     static_for<0, NV>([&](auto II) { act[II] = 0; });
@@ -1116,7 +1124,6 @@ REX_HD int forward(const Model<T>& m_in, const Lane<T>& L, const T* qpos, const 
       constexpr int u = UU; T c = hmin(hmax(ctrl[u], T(-0.4)), T(0.4)); act[kActDof[u]] += m.act_gear[u] * c; });
     static_for<0, NV>([&](auto II) { constexpr int i = II; K.qfrc_smooth[i] = -L.damping[i] * qvel[i] - qfrc_bias[i] + act[i]; });
     static_for<1, NJNT>([&](auto JJ) { constexpr int j = JJ; K.qfrc_smooth[j + 5] -= m.jnt_stiff[j] * qpos[j + 6]; });   // springref 0
-    // M right away: 185 values replace cinert + cdof (278) in the set that has to survive the collision phase
     crb(m, S, F);
     // observation inputs: stored, not kept -- and only by the evaluation the observation is taken from (the last of an env
     // step: 261 words per lane that 19 of 20 evaluations would write for nothing)
@@ -1125,10 +1132,6 @@ REX_HD int forward(const Model<T>& m_in, const Lane<T>& L, const T* qpos, const 
     static_for<0, NV>([&](auto II) { s.obs_qfrc_actuator[II] = act[II]; });
     }
   }
-  REX_FENCE(); REX_HSTAMP(t3); REX_HACC(K, HT_SMOOTH, t0, t3);
-  limit_rows(m, qpos, qvel, K, s);
-  REX_HSTAMP(t3b); REX_HACC(K, HT_LIMITS, t3, t3b);
-  collide(m, qvel, K, s);
   REX_FENCE(); REX_HSTAMP(t5);
   factor(F);
   for (int i = 0; i < NV; i++) K.qacc_smooth[i] = K.qfrc_smooth[i];
