@@ -1115,7 +1115,7 @@ REX_HD int forward(const Model<T>& m_in, const Lane<T>& L, const T* qpos, const 
     limit_rows(m, qpos, qvel, K, s);
     REX_HSTAMP(t3b); REX_HACC(K, HT_LIMITS, t3, t3b);
     collide(m, qvel, K, s);
-    REX_FENCE();
+    REX_FENCE(); REX_HSTAMP(t4);
     com_pos(m, L, S, s);   // (reads the joint anchors / axes kinematics left in the LDS column: before the dual overwrites it)
     T qfrc_bias[NV], act[NV];
     com_vel_rne(m, L, qvel, S, qfrc_bias);
@@ -1131,6 +1131,7 @@ REX_HD int forward(const Model<T>& m_in, const Lane<T>& L, const T* qpos, const 
     static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) s.obs_cinert[b][k] = S.cinert[b][k]; for (int k = 0; k < 6; k++) s.obs_cvel[b][k] = S.cvel[b][k]; s.obs_xipos_x[b] = S.xipos[b][0]; });
     static_for<0, NV>([&](auto II) { s.obs_qfrc_actuator[II] = act[II]; });
     }
+    REX_FENCE(); REX_HSTAMP(t4e); REX_HACC(K, HT_SMOOTH, t4, t4e);   // (HT_SMOOTH: kinematics + everything from com to M)
   }
   REX_FENCE(); REX_HSTAMP(t5);
   factor(F);
