@@ -44,9 +44,9 @@ constexpr int MAXCON = 64;   // contacts per evaluation (a counter on the device
 constexpr int MAXEFC = 192;  // constraint rows per evaluation
 constexpr int NXI = 30, NOBS = 376;
 enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3 };
-// dual-space PGS working set kept in LDS on the device (one contiguous column per lane): the packed lower triangle of
-// A = J M^-1 J^T + diag(R) for up to DUAL_NMAX rows (0.09% of the evaluations of a random-policy batch have more than
-// 16 rows, none more than 21), then b = J qacc_smooth - aref and 1 / A_ii
+// dual-space PGS working set kept in LDS on the device (one contiguous column per lane): A = J M^-1 J^T + diag(R) for up to
+// DUAL_NMAX rows (0.09% of the evaluations of a random-policy batch have more than 16 rows, none more than 21) -- square and
+// row-major up to 16 rows (pgs_sweeps_sq), the packed lower triangle above --, then b = J qacc_smooth - aref and 1 / A_ii
 constexpr int DUAL_NMAX = 21;
 constexpr int tri(int i) { return i * (i + 1) / 2; }
 constexpr int DUAL_B = tri(DUAL_NMAX), DUAL_DI = DUAL_B + DUAL_NMAX;
@@ -212,9 +212,10 @@ struct Lane {   // randomised part of the model (xi)
   T damping[NV];      // dof_damping
 };
 
-// Smooth-dynamics working set of one evaluation (kinematics -> com -> RNE -> CRB).  Every access uses compile-time
-// indices, so it lives in registers -- and only for that phase: what the observation needs later (cinert, cvel, xipos_x,
-// qfrc_actuator of the LAST evaluation, random_humanoid.py:193-204) is parked in Scratch, not kept live across the solver.
+// Smooth-dynamics working set of one evaluation (kinematics, then -- after the collision phase, forward() -- com -> RNE ->
+// CRB).  Every access uses compile-time indices, so it lives in registers; only the body frames (xmat, xipos) are alive across
+// the collision phase, and what the observation needs later (cinert, cvel, xipos_x, qfrc_actuator of the LAST evaluation,
+// random_humanoid.py:193-204) is parked in Scratch, not kept live across the solver.
 template <class T>
 struct Smooth {
   T xmat[NBODY][9], xipos[NBODY][3];
@@ -243,6 +244,8 @@ struct Scratch {   // runtime-indexed per-lane arrays (HIP scratch): contacts an
 #if !defined(__HIP_DEVICE_COMPILE__)
   T cpos[MAXCON][3], cdist[MAXCON]; int cdim[MAXCON], cb1[MAXCON], cb2[MAXCON];   // contact log: host builds only (tests); the engine never reads it
 #endif
+  // (the dual path, <= DUAL_NMAX rows, overwrites row j of J with z_j = D^-1 L^-T J_j^T while it builds A; MiJ / Adiag are
+  // the scratch-row PGS's, used for more rows than that)
   T J[MAXEFC][NV], MiJ[MAXEFC][NV], R[MAXEFC], aref[MAXEFC], Adiag[MAXEFC], force[MAXEFC];
   // parked between phases (plain stores / loads at fixed offsets; keeps them out of the register file while the solver runs)
   T obs_cinert[NBODY][10], obs_cvel[NBODY][6], obs_xipos_x[NBODY], obs_qfrc_actuator[NV];   // observation inputs
