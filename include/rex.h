@@ -118,11 +118,16 @@ int rex_reset(rex_t* h, const uint8_t* mask, float* obs_out, void* stream);
 int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
              uint8_t* truncated_out, float* terminal_obs_out, void* stream);
 
-/* Offline replay of logged transitions under candidate xi (get_full_mjstate + set_sim_state + step, random_hopper.py:128-152,
- * random_half_cheetah.py:136-158): one env.step per lane from the CALLER's qpos [dev, nq*batch], qvel [dev, nv*batch],
- * xi [dev, task_dim*batch], action [dev, act_dim*batch] into obs_out / reward_out / done_out, in ONE launch; nothing of the
- * handle is read back or changed (state, task, step / episode counters).  Hopper and half-cheetah, regular ids
- * (REX_ERR_UNSUPPORTED otherwise: use rex_set_task + rex_set_state + rex_step). */
+/* Offline replay of logged transitions under candidate xi (get_full_mjstate + set_sim_state + step: random_hopper.py:128-152,
+ * random_half_cheetah.py:136-158, random_walker2d.py:161-185, random_humanoid.py:244-270, and the Unmodeled task files'
+ * copies of them): one env.step per lane from the CALLER's qpos [dev, nq*batch], qvel [dev, nv*batch], xi [dev, task_dim*batch]
+ * (the reduced task for the Unmodeled ids), action [dev, act_dim*batch] into obs_out / reward_out / done_out.  Nothing of the
+ * handle is read back or changed: state, task, step / episode counters, diagnostic counters, RNG position.  Hopper and
+ * half-cheetah: ONE launch.  Walker2d: its per-env geometry follows the xi lengths (set_task rebuilds the model,
+ * random_walker2d.py:106-113), so a derive launch into replay scratch precedes the step launch.  Humanoid: the forward
+ * launch of set_state (data.xipos for mass_center(), jinja_mujoco_env.py:154) precedes it.  Unmodeled ids: one scatter
+ * launch places the reduced task over the handle's frozen rows in a scratch copy of the full xi block.  The scratch is
+ * allocated by the first such call.  RandomCartPole: REX_ERR_UNSUPPORTED (the reference has no such helpers for it). */
 int rex_replay(rex_t* h, const float* qpos, const float* qvel, const float* xi, const float* action,
                float* obs_out, float* reward_out, uint8_t* done_out, void* stream);
 

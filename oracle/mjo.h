@@ -163,6 +163,9 @@ int mjo_batch_step(int kind, int variant, int n, const double* qpos, const doubl
 int mjo_batch_rollout(int kind, int variant, int n, int steps, const double* qpos, const double* qvel,
                       const double* actions, const double* xi, double* qpos_out, double* qvel_out,
                       double* reward_sum, int nthreads);
+int mjo_batch_rollout_autoreset(int kind, int variant, int n, int steps, const double* qpos, const double* qvel,
+                                const double* actions, const double* xi, const double* qpos_reset, const double* qvel_reset,
+                                double* qpos_out, double* qvel_out, double* reward_sum, long long* resets_out, int nthreads);
 /* forward-dynamics probe: returns qacc, qacc_smooth, M, bias, nefc, ncon for one state */
 int mjo_probe_forward(int kind, const double* qpos, const double* qvel, const double* action,
                       const double* xi, double* qacc, double* qacc_smooth, double* qM,

@@ -225,6 +225,8 @@ typedef struct {
   int kind, variant, n, lo, hi, steps;
   const double *qpos, *qvel, *action, *xi;
   double *qpos_out, *qvel_out, *obs_out, *reward_out; unsigned char* done_out;
+  const double *qpos_reset, *qvel_reset;   /* auto-reset rollouts (bench.py's cpu_baseline): state a finished lane restarts from */
+  long long* resets_out;
 } BatchJob;
 
 static void* batch_worker(void* arg) {
@@ -242,11 +244,17 @@ static void* batch_worker(void* arg) {
     for (int k = 0; k < nq; k++) q[k] = j->qpos[(size_t)k * n + i];
     for (int k = 0; k < nv; k++) v[k] = j->qvel[(size_t)k * n + i];
     mjo_env_set_state(e, q, v);
-    double rsum = 0; int done = 0;
+    double rsum = 0; int done = 0; long long nreset = 0;
     for (int s = 0; s < j->steps; s++) {
       for (int k = 0; k < nu; k++) a[k] = j->action[((size_t)s * nu + k) * n + i];
       double r; done = mjo_env_step(e, a, obs, &r); rsum += r;
+      if (done && j->qpos_reset) {   /* the vectorised env's auto-reset: reset_model() state drawn by the caller */
+        for (int k = 0; k < nq; k++) q[k] = j->qpos_reset[(size_t)k * n + i];
+        for (int k = 0; k < nv; k++) v[k] = j->qvel_reset[(size_t)k * n + i];
+        mjo_env_set_state(e, q, v); nreset++;
+      }
     }
+    if (j->resets_out) j->resets_out[i] = nreset;
     for (int k = 0; k < nq; k++) j->qpos_out[(size_t)k * n + i] = e->data.qpos[k];
     for (int k = 0; k < nv; k++) j->qvel_out[(size_t)k * n + i] = e->data.qvel[k];
     if (j->obs_out) for (int k = 0; k < e->obs_dim; k++) j->obs_out[(size_t)k * n + i] = obs[k];
@@ -275,14 +283,23 @@ static int run_batch(BatchJob* proto, int nthreads) {
 int mjo_batch_step(int kind, int variant, int n, const double* qpos, const double* qvel, const double* action,
                    const double* xi, double* qpos_out, double* qvel_out, double* obs_out, double* reward_out,
                    unsigned char* done_out, int nthreads) {
-  BatchJob j = {kind, variant, n, 0, n, 1, qpos, qvel, action, xi, qpos_out, qvel_out, obs_out, reward_out, done_out};
+  BatchJob j = {kind, variant, n, 0, n, 1, qpos, qvel, action, xi, qpos_out, qvel_out, obs_out, reward_out, done_out, NULL, NULL, NULL};
   return run_batch(&j, nthreads);
 }
 
 int mjo_batch_rollout(int kind, int variant, int n, int steps, const double* qpos, const double* qvel,
                       const double* actions, const double* xi, double* qpos_out, double* qvel_out,
                       double* reward_sum, int nthreads) {
-  BatchJob j = {kind, variant, n, 0, n, steps, qpos, qvel, actions, xi, qpos_out, qvel_out, NULL, reward_sum, NULL};
+  BatchJob j = {kind, variant, n, 0, n, steps, qpos, qvel, actions, xi, qpos_out, qvel_out, NULL, reward_sum, NULL, NULL, NULL, NULL};
+  return run_batch(&j, nthreads);
+}
+
+/* the same rollout with the batched env's auto-reset: a lane whose step returns done restarts from (qpos_reset, qvel_reset)[lane]
+ * (reset_model() states drawn by the caller) -- what the GPU leg of bench.py does inside its timed region */
+int mjo_batch_rollout_autoreset(int kind, int variant, int n, int steps, const double* qpos, const double* qvel,
+                                const double* actions, const double* xi, const double* qpos_reset, const double* qvel_reset,
+                                double* qpos_out, double* qvel_out, double* reward_sum, long long* resets_out, int nthreads) {
+  BatchJob j = {kind, variant, n, 0, n, steps, qpos, qvel, actions, xi, qpos_out, qvel_out, NULL, reward_sum, NULL, qpos_reset, qvel_reset, resets_out};
   return run_batch(&j, nthreads);
 }
 

@@ -13,7 +13,8 @@ for eid in sys.argv[1:] or ["RandomHopper-v0"]:
     acts = [(torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1).cuda() for _ in range(8)]
     for k in range(100): env.step_soa(acts[k % 8])
     torch.cuda.synchronize()
-    out = (ctypes.c_ulonglong * 96)()   # rex_debug_ktime copies all 96 accumulators; _native.lib().rex_debug_ktime(out)
+    out = (ctypes.c_ulonglong * 96)()   # rex_debug_ktime copies all 96 accumulators
+    _native.lib().rex_debug_ktime(out)   # read-and-zero: drops what the 100 warm-up steps accumulated
     for k in range(100): env.step_soa(acts[k % 8])
     torch.cuda.synchronize()
     _native.lib().rex_debug_ktime(out); o = list(out)

@@ -354,8 +354,10 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
     dn = false;
   }
   if (fl.endless) dn = false;            // random_hopper.py:95-96
-  if (!finite) atomicAdd(s.counters + 0, 1ull);
-  if (capped && threadIdx.x == 0) atomicAdd(s.counters + 2, 1ull);
+  if (!fl.readonly) {   // (rex_replay: nothing of the handle is written, its counters included)
+    if (!finite) atomicAdd(s.counters + 0, 1ull);
+    if (capped && threadIdx.x == 0) atomicAdd(s.counters + 2, 1ull);
+  }
   int t = s.t[io] + 1;
   bool trunc = fl.time_limit && t >= fl.max_steps && !dn && !fl.readonly;     // gym TimeLimit
   bool d = dn || trunc;
@@ -542,16 +544,19 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
   bool finite = true;
   for (int k = 0; k < hum::NQ; k++) finite = finite && isfinite(q[k]);
   for (int k = 0; k < hum::NV; k++) finite = finite && isfinite(v[k]);
-  if (!finite) { atomicAdd(s.counters + 0, 1ull); dn = true; }     // a diverged lane ends its episode
-  if (kn.overflow) atomicAdd(s.counters + 3, 1ull);
+  if (!finite) dn = true;                                           // a diverged lane ends its episode
   if (fl.endless && finite) dn = false;
-  s.t[i] = t;
-  bool trunc = fl.time_limit && t >= fl.max_steps && !dn;
+  bool trunc = fl.time_limit && t >= fl.max_steps && !dn && !fl.readonly;
   bool d = dn || trunc;
-  for (int k = 0; k < hum::NQ; k++) (s.qpos + k * B)[i] = q[k];
-  for (int k = 0; k < hum::NV; k++) (s.qvel + k * B)[i] = v[k];
-  for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
-  s.done[i] = d ? 2 : 0;
+  if (!fl.readonly) {   // (rex_replay: nothing of the handle is written, its counters included)
+    if (!finite) atomicAdd(s.counters + 0, 1ull);
+    if (kn.overflow) atomicAdd(s.counters + 3, 1ull);
+    s.t[i] = t;
+    for (int k = 0; k < hum::NQ; k++) (s.qpos + k * B)[i] = q[k];
+    for (int k = 0; k < hum::NV; k++) (s.qvel + k * B)[i] = v[k];
+    for (int b = 0; b < hum::NBODY; b++) (s.aux + b * B)[i] = xp[b];
+    s.done[i] = d ? 2 : 0;
+  }
   reward[i] = r; done_out[i] = d ? 1 : 0;
   if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
 }
@@ -636,6 +641,9 @@ struct rex_env {
   std::vector<hipEvent_t> ev0, ev1;
   size_t ev_n = 0;              // launches recorded since the last enable / read
   unsigned long long launches = 0;   // rex_step calls since the last enable (sampling phase)
+  // rex_replay scratch (allocated by the first replay that needs it): the full xi block the Unmodeled ids' reduced task is
+  // scattered into, and walker2d's per-env geometry rows derived from the CALLER's xi lengths
+  float* rp_xi = nullptr; float* rp_rows = nullptr; int* d_map = nullptr;   // rp_rows: walker2d geometry rows / humanoid xipos rows
 };
 constexpr size_t EV_POOL = 8192;
 
@@ -867,6 +875,9 @@ extern "C" int rex_destroy(rex_t* h) {
   hipFree(h->dev.done); hipFree(h->dev.counters); hipFree(h->d_scratch); hipFree(h->d_chol);
   if (h->dev.geom) hipFree(h->dev.geom);
   if (h->dev.aux) hipFree(h->dev.aux);
+  if (h->rp_xi) hipFree(h->rp_xi);
+  if (h->rp_rows) hipFree(h->rp_rows);
+  if (h->d_map) hipFree(h->d_map);
   for (auto e : h->ev0) hipEventDestroy(e);
   for (auto e : h->ev1) hipEventDestroy(e);
   delete h;
@@ -979,7 +990,7 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   // every `timing`-th launch is bracketed by two events of the pool rex_enable_timing created (ring): the two event packets
   // cost ~8 us of stream time per launch, 9 % of a hopper step, so a throughput run samples (bench.py: every 8th launch)
   const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;
-  const size_t ev_slot = h->ev_n % EV_POOL;
+  const size_t ev_slot = timed ? h->ev_n % h->ev0.size() : 0;   // (timing > 0 implies a complete pool)
   if (timed) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
   switch (h->kind) {
 #if REX_EN_CARTPOLE
@@ -1010,30 +1021,75 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   return REX_OK;
 }
 
-// Offline replay (random_hopper.py:128-152 get_full_mjstate / set_sim_state + step): one env.step per lane
-// from the CALLER's (qpos, qvel, xi, action) straight into the caller's outputs -- one launch, no copies, and nothing of the
-// handle changes (its state, task, counters and RNG position stay where they were).
+// Offline replay (random_hopper.py:128-152, random_half_cheetah.py:136-158, random_walker2d.py:161-185,
+// random_humanoid.py:244-270: get_full_mjstate / set_sim_state + step): one env.step per lane from the CALLER's (qpos, qvel,
+// xi, action) straight into the caller's outputs, and nothing of the handle changes -- its state, task, counters and RNG
+// position stay where they were.  hopper / half-cheetah: ONE launch.  humanoid: the forward launch of set_state (data.xipos for
+// mass_center(), jinja_mujoco_env.py:154) into replay scratch, then the step launch.  walker2d: the per-env geometry is a function of the xi
+// lengths (its set_task rebuilds the model, random_walker2d.py:106-113), so the derive launch precedes the step launch, into
+// replay scratch of the handle.  Unmodeled ids: `xi` is the reduced task; one scatter launch places it over the handle's
+// frozen rows in a scratch copy of the full xi block first (random_hopper_unmodeled.py:71-76 ...).
+__global__ void replay_xi_kernel(float* __restrict__ dst, const float* __restrict__ frozen, const float* __restrict__ task,
+                                 const int* __restrict__ map, int full_dim, int task_dim, long long B) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  for (int k = 0; k < full_dim; k++) dst[(size_t)k * B + i] = frozen[(size_t)k * B + i];
+  for (int k = 0; k < task_dim; k++) dst[(size_t)map[k] * B + i] = task[(size_t)k * B + i];
+}
+
 extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const float* xi, const float* action,
                           float* obs_out, float* reward_out, uint8_t* done_out, void* stream) {
   if (!h || !qpos || !qvel || !xi || !action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_replay: null argument");
-  if (h->variant || (h->kind != REX_HOPPER && h->kind != REX_HALFCHEETAH))
-    return set_err(REX_ERR_UNSUPPORTED, "rex_replay: hopper / half-cheetah (regular ids) only; use set_task + set_state + step for the others");
+  if (h->kind == REX_CARTPOLE) return set_err(REX_ERR_UNSUPPORTED, "rex_replay: RandomCartPoleEnv has no get_full_mjstate / set_sim_state (random_cartpole.py)");
   HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t B = (size_t)h->B;
   DevState dev = h->dev;                    // the handle's device view with the state rows replaced by the caller's buffers
   dev.qpos = const_cast<float*>(qpos); dev.qvel = const_cast<float*>(qvel); dev.xi = const_cast<float*>(xi);
+  if (h->variant) {                          // reduced task -> scratch copy of the full xi block
+    if (!h->rp_xi) {
+      HIP_TRY(hipMalloc(&h->rp_xi, sizeof(float) * h->full_dim * B));
+      HIP_TRY(hipMalloc(&h->d_map, sizeof(int) * MAX_XI));
+      HIP_TRY(hipMemcpy(h->d_map, h->dr.map, sizeof(int) * MAX_XI, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(replay_xi_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, h->rp_xi, h->dev.xi, xi, h->d_map,
+                       h->full_dim, h->dims.task_dim, (long long)B);
+    HIP_TRY(hipGetLastError());
+    dev.xi = h->rp_xi;
+  }
+#if REX_EN_WALKER2D
+  if (h->kind == REX_WALKER2D) {             // geometry of the caller's xi lengths (what set_task's build_model does)
+    if (!h->rp_rows) HIP_TRY(hipMalloc(&h->rp_rows, sizeof(float) * kWalkerCompact * B));
+    dev.geom = h->rp_rows;
+    hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, (const unsigned char*)nullptr, 0, h->variant ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+  }
+#endif
   StepFlags flags = h->flags; flags.readonly = 1; flags.info = nullptr;
-  hipStream_t st = (hipStream_t)stream;
   const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;   // same sampling as rex_step
-  const size_t ev_slot = h->ev_n % EV_POOL;
+  const size_t ev_slot = timed ? h->ev_n % h->ev0.size() : 0;
   if (timed) HIP_TRY(hipEventRecord(h->ev0[ev_slot], st));
-  if (h->kind == REX_HOPPER) {
+  switch (h->kind) {
 #if REX_EN_HOPPER
-    launch_planar_step<HopperSpec>(h, dev, flags, h->g_hopper, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
+    case REX_HOPPER: launch_planar_step<HopperSpec>(h, dev, flags, h->g_hopper, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st); break;
 #endif
-  } else {
 #if REX_EN_HALFCHEETAH
-    launch_planar_step<HalfCheetahSpec>(h, dev, flags, h->g_cheetah, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st);
+    case REX_HALFCHEETAH: launch_planar_step<HalfCheetahSpec>(h, dev, flags, h->g_cheetah, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st); break;
 #endif
+#if REX_EN_WALKER2D
+    case REX_WALKER2D: launch_planar_step<Walker2dSpec>(h, dev, flags, h->g_walker, action, obs_out, reward_out, done_out, nullptr, nullptr, 0, 0, st); break;
+#endif
+#if REX_EN_HUMANOID
+    case REX_HUMANOID:   // set_state's sim.forward() (jinja_mujoco_env.py:154) leaves data.xipos for mass_center(): a forward launch into
+                         // replay scratch, then the step launch
+      if (!h->rp_rows) HIP_TRY(hipMalloc(&h->rp_rows, sizeof(float) * hum::NBODY * B));
+      dev.aux = h->rp_rows;
+      hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, (float*)nullptr);
+      hipLaunchKernelGGL(humanoid_step_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, flags, action, obs_out, reward_out, done_out,
+                         (unsigned char*)nullptr, (float*)nullptr);
+      break;
+#endif
+    default: break;
   }
   if (timed) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
   HIP_TRY(hipGetLastError());
@@ -1117,19 +1173,30 @@ extern "C" int rex_enable_timing(rex_t* h, int enable) {
   if (enable && h->ev0.empty()) {   // the only place events are created: rex_step never allocates
     HIP_TRY(hipSetDevice(h->device));
     h->ev0.reserve(EV_POOL); h->ev1.reserve(EV_POOL);
-    for (size_t k = 0; k < EV_POOL; k++) {
-      hipEvent_t a, c; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&c)); h->ev0.push_back(a); h->ev1.push_back(c);
+    hipError_t err = hipSuccess;
+    for (size_t k = 0; k < EV_POOL && err == hipSuccess; k++) {
+      hipEvent_t a = nullptr, c = nullptr;
+      err = hipEventCreate(&a);
+      if (err == hipSuccess) { err = hipEventCreate(&c); if (err != hipSuccess) hipEventDestroy(a); }
+      if (err == hipSuccess) { h->ev0.push_back(a); h->ev1.push_back(c); }
+    }
+    if (err != hipSuccess) {   // all or nothing: a partial pool would be indexed past its end by the ring
+      for (auto e : h->ev0) hipEventDestroy(e);
+      for (auto e : h->ev1) hipEventDestroy(e);
+      h->ev0.clear(); h->ev1.clear(); h->timing = 0;
+      return set_err(REX_ERR_HIP, "rex_enable_timing: hipEventCreate failed: %s", hipGetErrorString(err));
     }
   }
-  h->timing = enable > 0 ? enable : 0; h->ev_n = 0; h->launches = 0;
+  h->timing = (enable > 0 && !h->ev0.empty()) ? enable : 0; h->ev_n = 0; h->launches = 0;
   return REX_OK;
 }
 extern "C" int rex_read_timing(rex_t* h, float* ms_out, int max_n) {
   if (!h || !ms_out) { set_err(REX_ERR_ARG, "rex_read_timing: null argument"); return REX_ERR_ARG; }
   int n = 0;
-  const size_t first = h->ev_n > EV_POOL ? h->ev_n - EV_POOL : 0;   // the ring keeps the last EV_POOL launches
-  for (size_t k = first; k < h->ev_n && n < max_n; k++) {
-    const size_t slot = k % EV_POOL;
+  const size_t pool = h->ev0.size();
+  const size_t first = h->ev_n > pool ? h->ev_n - pool : 0;   // the ring keeps the last `pool` launches
+  for (size_t k = first; pool && k < h->ev_n && n < max_n; k++) {
+    const size_t slot = k % pool;
     if (hipEventSynchronize(h->ev1[slot]) != hipSuccess) break;
     float ms = 0; if (hipEventElapsedTime(&ms, h->ev0[slot], h->ev1[slot]) != hipSuccess) break;
     ms_out[n++] = ms;

@@ -1,16 +1,33 @@
-"""Minimal stable-baselines3 ``VecEnv``-protocol adapter (duck-typed: stable-baselines3 itself is not a
-dependency).  The reference's downstream (README.md:68, sb3-gym-interface) drives envs through
-``reset() -> obs``, ``step_async(actions)``, ``step_wait() -> (obs, rewards, dones, infos)`` with numpy arrays
-and auto-reset + ``infos[i]["terminal_observation"]`` -- the semantics VecRandomEnv already has on device."""
+"""stable-baselines3 ``VecEnv`` adapter (README.md:68: the reference's downstream, sb3-gym-interface, drives envs through
+``reset() -> obs``, ``step_async(actions)``, ``step_wait() -> (obs, rewards, dones, infos)`` with numpy arrays, auto-reset and
+``infos[i]["terminal_observation"]`` -- the semantics VecRandomEnv already has on device).
+
+When ``stable_baselines3`` is importable the adapter IS a ``stable_baselines3.common.vec_env.VecEnv`` (real callers check
+``isinstance``), and its spaces are real gymnasium / gym spaces (vec_env.make_spaces); otherwise it is the same class over
+``object`` -- neither package is a dependency of the hot path."""
 import numpy as np
 
 
-class SB3VecEnvAdapter:
+def _vecenv_base():
+    try:
+        from stable_baselines3.common.vec_env import VecEnv
+        return VecEnv
+    except Exception:
+        return object
+
+
+class _AdapterBody:
+    """Everything the adapter does; mixed with the base class chosen at import time (adapter_class)."""
+
     def __init__(self, env):
         self.env = env
-        self.num_envs = env.batch
-        self.observation_space = env.observation_space
-        self.action_space = env.action_space
+        base = _vecenv_base()
+        if base is not object:
+            base.__init__(self, env.batch, env.observation_space, env.action_space)
+        else:
+            self.num_envs = env.batch
+            self.observation_space = env.observation_space
+            self.action_space = env.action_space
         self._actions = None
 
     def reset(self):
@@ -70,3 +87,12 @@ class SB3VecEnvAdapter:
     def export_lane(self, k=0):
         """Host snapshot (qpos, qvel, xi) of env k for an external viewer (rendering stays off the GPU path)."""
         return self.env.export_lane(k)
+
+
+def adapter_class():
+    """The adapter class over ``stable_baselines3.common.vec_env.VecEnv`` when that is importable, over ``object`` otherwise."""
+    base = _vecenv_base()
+    return type("SB3VecEnvAdapter", (_AdapterBody,) if base is object else (_AdapterBody, base), {"__doc__": _AdapterBody.__doc__})
+
+
+SB3VecEnvAdapter = adapter_class()

@@ -13,16 +13,37 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def world_size():
+    """Ranks of the initialised process group (what RCCL / gloo actually sees), else WORLD_SIZE from the environment."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return dist_env()[2]
+
+
 def shard(batch_per_rank, rank):
     """(env_offset, batch) of this rank under weak scaling."""
     return rank * batch_per_rank, batch_per_rank
 
 
-def shard_strong(global_batch, rank, world):
-    """(env_offset, batch) of this rank when a fixed global batch is split (remainder to low ranks)."""
-    q, r = divmod(global_batch, world)
-    b = q + (1 if rank < r else 0)
-    off = rank * q + min(rank, r)
+WAVE_ENVS = 32   # envs per wavefront of the step kernels: the solver instantiation is picked per wave (DESIGN.md section 4)
+
+
+def shard_strong(global_batch, rank, world, align=WAVE_ENVS):
+    """(env_offset, batch) of this rank when a fixed global batch is split.  Shard boundaries fall on multiples of `align`
+    envs (one wavefront of the step kernels) wherever the batch allows it, so that every wave holds the same envs as in the
+    single-GPU run and an index-sharded run reproduces it bit for bit under the default solver knobs too (the arithmetic of
+    a lane depends on which instantiation its WAVE picks); the remainder goes to the low ranks, the last rank takes what
+    is left."""
+    align = max(int(align), 1)
+    blocks, tail = divmod(global_batch, align)
+    if blocks < world:           # fewer whole waves than ranks: plain split
+        q, r = divmod(global_batch, world)
+        return rank * q + min(rank, r), q + (1 if rank < r else 0)
+    q, r = divmod(blocks, world)
+    nb = q + (1 if rank < r else 0)
+    off = (rank * q + min(rank, r)) * align
+    b = nb * align + (tail if rank == world - 1 else 0)
     return off, b
 
 
@@ -60,22 +81,26 @@ def reduce_counter_and_time(steps_done, elapsed_s, device):
 
 class StepCounter:
     """The path's ONLY collective: the global env-step counter, summed over ranks
-    asynchronously every `every` steps so it never sits on the step critical path.  `add()` is called once per
-    batched step; every `every`-th call snapshots the local count into a staging tensor and issues
-    ``all_reduce(SUM, async_op=True)`` (RCCL runs it on its own stream; gloo on its worker thread); the previous
-    reduction is waited for only when the next one is issued.  `total()` drains and returns the exact global
-    count.  At world size 1 it is a plain integer."""
+    asynchronously every `every` steps and never on the step's critical path.  `add()` is called once per batched
+    step; every `every`-th call writes the HOST-side local count into one of two staging tensors and issues
+    ``all_reduce(SUM, async_op=True)`` on a side stream of its own (RCCL orders the collective behind that stream, not
+    behind the compute stream; gloo runs it on its worker thread).  Nothing is read back while stepping: the host waits
+    only for the reduction issued TWO rounds earlier (the one whose staging tensor it is about to reuse -- long
+    finished), and the compute stream is never made to wait.  `total()` issues a last reduction, drains and returns
+    the exact global count.  At world size 1 it is a plain integer."""
 
     def __init__(self, device, every=256):
         import torch
         import torch.distributed as dist
+        self._torch = torch
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.every = max(int(every), 1)
         self.local = 0            # env-steps of this rank
         self.n_calls = 0
-        self.last_global = 0      # most recent completed global sum (lags by < 2 * every steps)
-        self._work = None
-        self._buf = torch.zeros(1, dtype=torch.int64, device=device)
+        self.last_global = 0      # result of the most recent reduction that total() / poll() has read back
+        self._bufs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
+        self._works = [None, None]
+        self._side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.reductions = 0
 
     def add(self, env_steps):
@@ -84,23 +109,27 @@ class StepCounter:
         if self._dist is not None and self.n_calls % self.every == 0:
             self._issue()
 
-    def _issue(self):
-        self._drain()
-        self._buf.fill_(self.local)
-        self._work = self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, async_op=True)
-        self.reductions += 1
+    def _ctx(self):
+        import contextlib
+        return self._torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
 
-    def _drain(self):
-        if self._work is not None:
-            self._work.wait()
-            self.last_global = int(self._buf.item())
-            self._work = None
+    def _issue(self):
+        k = self.reductions % 2
+        with self._ctx():
+            if self._works[k] is not None:     # two rounds old: complete long ago (RCCL: a stream-side wait on the side stream)
+                self._works[k].wait()
+            self._bufs[k].fill_(self.local)
+            self._works[k] = self._dist.all_reduce(self._bufs[k], op=self._dist.ReduceOp.SUM, async_op=True)
+        self.reductions += 1
+        return k
 
     def total(self):
         if self._dist is None:
             return self.local
-        self._issue()
-        self._drain()
+        k = self._issue()
+        with self._ctx():
+            self._works[k].wait()
+            self.last_global = int(self._bufs[k].item())   # the only read-back: after the timed region
         return self.last_global
 
 

@@ -17,16 +17,59 @@ from .specs import MAX_EPISODE_STEPS, SPECS, UNMODELED_SPECS
 
 
 class _Box:
+    """Stand-in with the attributes callers read from ``gym.spaces.Box`` -- used only when neither gymnasium nor gym is
+    importable (this image); with either installed the real classes are built (:func:`make_spaces`)."""
     def __init__(self, low, high, shape, dtype=np.float32):
         self.low = np.full(shape, low, dtype=dtype)
         self.high = np.full(shape, high, dtype=dtype)
-        self.shape, self.dtype = tuple(shape), dtype
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0); hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
 
 
 class _Discrete:
     def __init__(self, n):
         self.n = n
-        self.shape, self.dtype = (), np.int64
+        self.shape, self.dtype = (), np.dtype(np.int64)
+
+    def contains(self, x):
+        return 0 <= int(x) < self.n
+
+    def sample(self):
+        return int(np.random.randint(self.n))
+
+
+def spaces_module():
+    """``gymnasium.spaces`` or ``gym.spaces``, whichever is importable (gymnasium first: what current stable-baselines3
+    checks ``isinstance(space, spaces.Box)`` against), else None."""
+    for name in ("gymnasium", "gym"):
+        try:
+            return __import__(name + ".spaces", fromlist=["spaces"])
+        except Exception:
+            continue
+    return None
+
+
+def make_spaces(dims):
+    """(observation_space, action_space) of one env as the reference builds them: action bounds from
+    ``actuator_ctrlrange`` (jinja_mujoco_env.py:99-103; Discrete(2) for the cart-pole, random_cartpole.py:96), observation
+    ``Box(-inf, inf)`` over the observation vector (jinja_mujoco_env.py:23-36) -- float32, the dtype the batched env
+    returns.  Real gymnasium / gym spaces when one of them is importable, the duck-typed stand-ins otherwise."""
+    sp = spaces_module()
+    obs_shape, act_shape = (int(dims.obs_dim),), (int(dims.act_dim),)
+    if sp is not None:
+        obs = sp.Box(low=-np.inf, high=np.inf, shape=obs_shape, dtype=np.float32)
+        act = sp.Discrete(2) if dims.discrete_action else sp.Box(low=np.float32(dims.act_low), high=np.float32(dims.act_high),
+                                                                 shape=act_shape, dtype=np.float32)
+        return obs, act
+    return (_Box(-np.inf, np.inf, obs_shape),
+            _Discrete(2) if dims.discrete_action else _Box(dims.act_low, dims.act_high, act_shape))
 
 
 class VecRandomEnv(DRConfig):
@@ -54,11 +97,7 @@ class VecRandomEnv(DRConfig):
         self.noisy = bool(noisy)
         self.max_episode_steps = MAX_EPISODE_STEPS
         self.autoreset, self.time_limit = bool(autoreset), bool(time_limit)
-        if dims.discrete_action:
-            self.action_space = _Discrete(2)                                  # random_cartpole.py:96
-        else:
-            self.action_space = _Box(dims.act_low, dims.act_high, (dims.act_dim,))   # jinja_mujoco_env.py:99-103
-        self.observation_space = _Box(-np.inf, np.inf, (dims.obs_dim,))
+        self.observation_space, self.action_space = make_spaces(dims)       # gymnasium / gym spaces when importable
         f32 = dict(dtype=torch.float32, device=self.device)
         B = self.batch
         self._obs = torch.zeros(dims.obs_dim, B, **f32)
@@ -258,9 +297,15 @@ class VecRandomEnv(DRConfig):
     def replay_transitions(self, obs, action, xi=None):
         """One logged transition per env under this env's (or the given) xi: set_sim_state(get_full_mjstate(obs)),
         step(action) without auto-reset side effects -> next observation.  The massively parallel inner loop of
-        offline system identification (many candidate xi x one transition each)."""
-        if self.kind in ("hopper", "halfcheetah") and not self.unmodeled:
-            return self._replay_fused(obs, action, self.get_task() if xi is None else xi)
+        offline system identification (many candidate xi x one transition each).  Every MuJoCo chain and id goes
+        through `rex_replay` (caller buffers in, caller buffers out, the env untouched)."""
+        if self.kind == "cartpole":
+            raise NotImplementedError("RandomCartPoleEnv has no get_full_mjstate / set_sim_state (random_cartpole.py)")
+        return self._replay_fused(obs, action, self.get_task() if xi is None else xi)
+
+    def replay_three_call(self, obs, action, xi=None):
+        """The same transition through the reference's own call sequence (set_task + set_sim_state + step on the env
+        itself, auto-reset off): what `rex_replay` is checked against."""
         keep = self.autoreset
         self.autoreset = False; self._push_flags()
         try:
@@ -274,10 +319,11 @@ class VecRandomEnv(DRConfig):
             self.autoreset = keep; self._push_flags()
 
     def replay_soa(self, qpos_soa, qvel_soa, xi_soa, action_soa):
-        """Zero-copy fused replay (hopper, half-cheetah): ONE kernel launch reads the caller's contiguous SoA device tensors
-        -- qpos [nq, batch] (root x zeroed, as get_full_mjstate gives it), qvel [nv, batch], xi [task_dim, batch], action
-        [act_dim, batch] -- and writes next observation / reward / done into buffers of this object (valid until the next
-        replay call); the env itself (state, task, counters, RNG position) is not touched."""
+        """Zero-copy replay through `rex_replay`: reads the caller's contiguous SoA device tensors -- qpos [nq, batch] (root x
+        zeroed, as get_full_mjstate gives it), qvel [nv, batch], xi [task_dim, batch], action [act_dim, batch] -- and writes
+        next observation / reward / done into buffers of this object (valid until the next replay call); the env itself
+        (state, task, counters, RNG position) is not touched.  One launch for hopper / half-cheetah; walker2d, the humanoid
+        and the Unmodeled ids add the launch their set_task / set_state needs (include/rex.h)."""
         t = self._torch
         if not hasattr(self, "_rp_obs"):
             self._rp_obs = t.empty(self.dims.obs_dim, self.batch, dtype=t.float32, device=self.device)
@@ -298,6 +344,15 @@ class VecRandomEnv(DRConfig):
         self._replay_keep = keep              # alive until the launch has consumed them (stream-ordered)
         o, r, d = self.replay_soa(*keep)
         return o.t().clone(), r.clone(), d.bool()
+
+    def set_model_args(self, size):           # jinja_mujoco_env.py:89-90 (the template's `size` list; walker2d: xi[7:11])
+        """Walker2d: the four link lengths of the Jinja template, for every env (the rest of the task is kept); the other
+        chains have no per-env template arguments here (their `size` lists are compile-time constants of the kernels)."""
+        if self.kind != "walker2d" or self.unmodeled:
+            raise NotImplementedError("set_model_args: only RandomWalker2d-v0 rebuilds its model from template arguments")
+        xi = self.get_task().clone()
+        xi[:, 7:11] = self._torch.as_tensor(np.asarray(size, dtype=np.float32), device=self.device).reshape(-1, 4)
+        self.set_task(xi)
 
     def state_vector(self):                   # jinja_mujoco_env.py:231-235
         q, v = self.get_state()

@@ -73,6 +73,21 @@ def oracle_rollout(kind, qpos, qvel, actions, xi, nthreads=8, tolerance=0.0):
     return dict(qpos=qo.T.copy(), qvel=vo.T.copy(), reward_sum=r)
 
 
+def oracle_rollout_autoreset(kind, qpos, qvel, actions, xi, qpos_reset, qvel_reset, nthreads=8, tolerance=0.0):
+    """oracle_rollout with the batched env's auto-reset: a lane whose step returns done restarts from its row of
+    (qpos_reset, qvel_reset).  Returns the end state, the reward sums and the number of resets per lane."""
+    d = DIMS[kind]; L = lib(); L.mjo_set_tolerance(tolerance)
+    q, v, x = _soa(qpos, d["nq"]), _soa(qvel, d["nv"]), _soa(xi, d["nx"])
+    qr, vr = _soa(qpos_reset, d["nq"]), _soa(qvel_reset, d["nv"])
+    n = q.shape[1]
+    acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).transpose(0, 2, 1))   # [steps][nu][n]
+    qo = np.zeros_like(q); vo = np.zeros_like(v); r = np.zeros(n); resets = np.zeros(n, dtype=np.int64)
+    rc = L.mjo_batch_rollout_autoreset(KINDS[kind], 0, n, acts.shape[0], _p(q), _p(v), _p(acts), _p(x), _p(qr), _p(vr), _p(qo), _p(vo),
+                                       _p(r), resets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), nthreads)
+    assert rc == 0
+    return dict(qpos=qo.T.copy(), qvel=vo.T.copy(), reward_sum=r, resets=resets)
+
+
 def oracle_forward(kind, qpos, qvel, action, xi, tolerance=1e-12):
     d = DIMS[kind]; L = lib(); L.mjo_set_tolerance(tolerance)
     nv = d["nv"]

@@ -128,10 +128,14 @@ def test_state_helpers_and_replay(torch_mod):
     xi = (nom * np.random.RandomState(0).uniform(.7, 1.3, (B, 4))).astype(np.float32)
     a = torch.rand(1, 3) * 2 - 1
     nxt, r, d = env.replay_transitions(o[:1].expand(B, -1), a.expand(B, -1), xi)
-    ref = oracle_batch_step("hopper", fq[:1].expand(B, -1).cpu().numpy().astype(np.float64), fv[:1].expand(B, -1).cpu().numpy().astype(np.float64),
-                            a.expand(B, -1).numpy().astype(np.float64), xi.astype(np.float64))
-    err = np.abs(nxt.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
-    assert np.percentile(err, 99) < 2e-4
+    from oracle_bindings import oracle_sensitivity
+    from parity_util import assert_lanes_explained
+    ref, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_batch_step("hopper", q_, v_, a_, x_),
+                                   [fq[:1].expand(B, -1).cpu().numpy().astype(np.float64), fv[:1].expand(B, -1).cpu().numpy().astype(np.float64),
+                                    a.expand(B, -1).numpy().astype(np.float64), xi.astype(np.float64)], ["obs"])
+    os_ = 1 + np.abs(ref["obs"]).max(1)
+    err = np.abs(nxt.cpu().numpy() - ref["obs"]).max(1) / os_
+    assert_lanes_explained(err, sens["obs"] / os_, 2e-4, 2e-2, label="hopper replay |dobs|rel")      # every lane
     assert nxt.std(0).max() > 1e-4          # different xi -> different next states
     env.close()
 

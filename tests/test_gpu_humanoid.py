@@ -68,9 +68,12 @@ def test_step_parity_and_second_step(torch_mod, lanes):
     a2 = np.random.RandomState(9).uniform(-.4, .4, (n, 17)).astype(np.float32).astype(np.float64)
     q1, v1 = qq.cpu().numpy().astype(np.float64), vv.cpu().numpy().astype(np.float64)
     obs2, r2, d2, _ = env.step(torch.as_tensor(a2, dtype=torch.float32))
-    ref2 = oracle_humanoid_step(q1, v1, a2, xi, xipos_x_prev=ref["xipos_x"])
+    ref2, sens2 = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_humanoid_step(q_, v_, a_, x_, xipos_x_prev=ref["xipos_x"]),
+                                     [q1, v1, a2, xi], ["reward", "obs"], trials=2)
     er2 = np.abs(r2.cpu().numpy() - ref2["reward"])
-    assert np.percentile(er2, 99) < 5e-3, np.percentile(er2, 99)
+    assert_lanes_explained(er2, sens2["reward"], 5e-3, 2e-1, label=tag + " second step |dreward|")      # every lane
+    os2 = 1 + np.abs(ref2["obs"]).max(1)
+    assert_lanes_explained(np.abs(obs2.cpu().numpy() - ref2["obs"]).max(1) / os2, sens2["obs"] / os2, TOL_OBS, CAP_OBS, label=tag + " second step |dobs|rel")
     c = env.counters(); assert c["nonfinite"] == 0 and c["overflow"] == 0
     env.close()
 
@@ -174,7 +177,8 @@ def test_humanoid_unmodeled_id(torch_mod):
     """RandomHumanoidUnmodeled-v0: masses 1..4 and dampings 6..8 frozen at 0.8x, 23-dim task
     (random_humanoid_unmodeled.py:40-53)."""
     import random_envs_amd as rex
-    from oracle_bindings import oracle_batch_step
+    from oracle_bindings import oracle_batch_step, oracle_sensitivity
+    from parity_util import assert_lanes_explained
     torch = torch_mod
     n = 256
     env = rex.make("RandomHumanoidUnmodeled-v0", batch=n, autoreset=False)
@@ -185,10 +189,12 @@ def test_humanoid_unmodeled_id(torch_mod):
     xi = (nom * np.random.RandomState(2).uniform(.8, 1.2, (n, 23))).astype(np.float32).astype(np.float64)
     env.set_task(xi.astype(np.float32)); env.set_state(q, v)
     obs, r, d, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
-    ref = oracle_batch_step("humanoid", q, v, a, xi, variant=1, tolerance=0.0)
-    eo = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
-    assert np.percentile(eo, 99) < 2e-4, eo.max()
-    assert np.percentile(np.abs(r.cpu().numpy() - ref["reward"]), 99) < 2e-3
+    ref, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_batch_step("humanoid", q_, v_, a_, x_, variant=1, tolerance=0.0),
+                                   [q, v, a, xi], ["obs", "reward"], trials=2)
+    os_ = 1 + np.abs(ref["obs"]).max(1)
+    eo = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / os_
+    assert_lanes_explained(eo, sens["obs"] / os_, TOL_OBS, CAP_OBS, label="humanoid unmodeled |dobs|rel")        # every lane
+    assert_lanes_explained(np.abs(r.cpu().numpy() - ref["reward"]), sens["reward"], TOL_REW, CAP_REW, label="humanoid unmodeled |dreward|")
     env.close()
 
 

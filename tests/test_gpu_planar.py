@@ -201,7 +201,8 @@ def test_full_batch_finite_and_deterministic(torch_mod, kind, B):
 def test_unmodeled_ids(torch_mod, kind, eid):
     """same kernels, reduced task vector, frozen 0.8x prefix (test.py's source env)."""
     import random_envs_amd as rex
-    from oracle_bindings import DIMS, UNMODELED_NX, oracle_batch_step
+    from oracle_bindings import DIMS, UNMODELED_NX, oracle_batch_step, oracle_sensitivity
+    from parity_util import assert_lanes_explained
     torch = torch_mod
     n = 512; d = DIMS[kind]; nx = UNMODELED_NX[kind]
     env = rex.make(eid, batch=n, seed=3, autoreset=False)
@@ -217,18 +218,21 @@ def test_unmodeled_ids(torch_mod, kind, eid):
     # (1) freshly constructed env (no set_task yet): frozen prefix at 0.8x nominal
     env.set_state(q, v)
     obs, r, dn, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
-    ref = oracle_batch_step(kind, q, v, a, np.full((n, nx), np.nan), variant=1)
-    e0 = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
-    assert np.percentile(e0, 99) < 2e-4, e0.max()
+    step1 = lambda q_, v_, a_, x_: oracle_batch_step(kind, q_, v_, a_, x_, variant=1)
+    ref, sens = oracle_sensitivity(step1, [q, v, a, np.full((n, nx), np.nan)], ["obs"])
+    os_ = 1 + np.abs(ref["obs"]).max(1)
+    e0 = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / os_
+    assert_lanes_explained(e0, sens["obs"] / os_, 2e-4, 2e-2, label=eid + " fresh |dobs|rel")      # every lane
     # (2) after set_task with a random reduced task
     lo = np.array([b[0] for b in env.spec.search_bounds]); hi = np.array([b[1] for b in env.spec.search_bounds])
     xi = (nom * rng.uniform(0.8, 1.2, (n, nx))).clip(lo, hi).astype(np.float32).astype(np.float64)
     env.set_task(xi.astype(np.float32)); env.set_state(q, v)
     assert np.allclose(env.get_task().cpu().numpy(), xi, rtol=1e-6)
     obs, r, dn, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
-    ref = oracle_batch_step(kind, q, v, a, xi, variant=1)
-    e1 = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
-    assert np.percentile(e1, 99) < 2e-4, e1.max()
+    ref, sens = oracle_sensitivity(step1, [q, v, a, xi], ["obs"])
+    os_ = 1 + np.abs(ref["obs"]).max(1)
+    e1 = np.abs(obs.cpu().numpy() - ref["obs"]).max(1) / os_
+    assert_lanes_explained(e1, sens["obs"] / os_, 2e-4, 2e-2, label=eid + " set_task |dobs|rel")
     # (3) test.py's scenario: uniform DR on the source env, then reset resamples only the reduced task
     env.set_dr_distribution("uniform", np.stack([lo * 1.1, np.minimum(hi, lo * 1.1 + 1.0)], 1).ravel().tolist())
     env.set_dr_training(True); env.reset()

@@ -266,7 +266,10 @@ def test_replay_transitions_every_chain(torch_mod, eid):
         inv = list(range(45)) + list(range(269, 292))
         err = ((nxt[:, inv] - ref[:, inv]).abs() / (1 + ref[:, inv].abs())).max().item()
         assert err < 2e-4, err
-        assert (r - rr).abs().max().item() < 2e-2 and (d != dd).float().mean().item() < 0.01
+        assert (r - rr).abs().max().item() < 2e-2
+        zz = ref[:, 0]                                                          # done = z < 1 or z > 2: may differ only at a threshold
+        far = ((zz - 1.0).abs() > 1e-4) & ((zz - 2.0).abs() > 1e-4)
+        assert torch.equal(d[far], dd[far])
     else:     # the planar kernels integrate from x = 0 anyway: bit-identical
         assert torch.equal(nxt, ref) and torch.equal(r, rr) and torch.equal(d, dd)
     env.close(); env2.close()

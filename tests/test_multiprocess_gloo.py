@@ -58,12 +58,13 @@ def test_two_rank_gloo_sharding_and_counter(tmp_path):
     assert [d["off"] for d in outs] == [0, 32768]
     assert all(d["total"] == 10 * 32768 * 2 + 1 for d in outs)          # SUM over ranks
     assert all(d["tmax"] == 2.0 and d["tmax2"] == 2.0 for d in outs)    # MAX over ranks
-    # asynchronous counter: exact total after the drain, 3 in-loop reductions + the final one; the running value the
-    # ranks see lags (the reduction issued at step 16 is the newest one waited for inside the loop)
+    # asynchronous counter: exact total after the drain, 3 in-loop reductions + the final one; nothing is read back while
+    # stepping (a read-back is a blocking device-to-host copy: it would drain the launch queue every `every` steps)
     assert all(d["atotal"] == 25 * (2 * 32768 + 1) and d["nred"] == 4 for d in outs)
-    assert all(d["lag"] == 16 * (2 * 32768 + 1) for d in outs)
-    # strong split covers the global batch exactly once
+    assert all(d["lag"] == 0 for d in outs)
+    # strong split covers the global batch exactly once, the boundary on a whole wavefront (32 envs)
     assert outs[0]["so"] == 0 and outs[1]["so"] == outs[0]["sb"] and outs[0]["sb"] + outs[1]["sb"] == 32769
+    assert outs[1]["so"] % 32 == 0
 
 
 def test_shard_strong_partition():
@@ -74,3 +75,6 @@ def test_shard_strong_partition():
             off, b = sharding.shard_strong(32768 + 5, r, world)
             cover += list(range(off, off + b))
         assert cover == list(range(32768 + 5))
+        # every boundary on a whole wavefront of the step kernels: sharded runs reproduce the single-GPU waves
+        assert all(sharding.shard_strong(32768 + 5, r, world)[0] % sharding.WAVE_ENVS == 0 for r in range(world))
+    assert sharding.shard_strong(40, 1, 4) == (10, 10)    # fewer whole waves than ranks: plain split
