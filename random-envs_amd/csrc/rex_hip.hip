@@ -425,25 +425,30 @@ __device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepF
   }
 }
 
+// pending_bit: walker2d's auto-reset under DR -- the lane's geometry has to follow its NEW xi lengths, which is the derive
+// launch behind this one; the auto-reset mask is s.done itself and reset_lane clears it, so the reset leaves this bit for
+// walker_derive_kernel to find (and clear).
 template <class S>
 __global__ void __launch_bounds__(64) planar_reset_kernel(DevState s, StepFlags fl, DRParams dr, int resample, int reset_state,
                                                           const unsigned char* __restrict__ mask, int mask_bit,
-                                                          float* __restrict__ obs) {
+                                                          float* __restrict__ obs, int pending_bit) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   planar_reset_lane<S>(s, fl, dr, resample, reset_state, i, obs);
+  if (pending_bit) s.done[i] = (unsigned char)pending_bit;
 }
 
 #if REX_EN_WALKER2D
 // walker2d: re-derive the per-env model constants from the xi lengths for the masked lanes
 // (replaces build_model() inside RandomWalker2dEnv.set_task, random_walker2d.py:106-113).
-__global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* __restrict__ mask, int mask_bit,
-                                                           int refresh_frozen_masses) {
+__global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const unsigned char* mask, int mask_bit,
+                                                           int refresh_frozen_masses, int clear_pending) {
   using S = Walker2dSpec;
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
+  if (clear_pending) s.done[i] = 0;   // (mask is s.done: the pending bit planar_reset_kernel left)
   double size[4];
   for (int k = 0; k < 4; k++) size[k] = (double)s.xi[(long long)(7 + k) * s.B + i];
   PlanarGeom<double, S> G; SolParams<double> sp; double nominal[S::NB];
@@ -731,10 +736,12 @@ static size_t hum_lds_bytes(const rex_env* h) { return sizeof(float) * hum::DUAL
 static unsigned grid_for(const rex_env* h) { return (unsigned)((h->B + h->lanes - 1) / h->lanes); }
 static unsigned lanes_of(const rex_env* h) { return (unsigned)h->lanes; }
 
+constexpr int DERIVE_PENDING_BIT = 4;   // in DevState::done: reset under DR, geometry not yet re-derived (walker2d auto-reset)
 static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, hipStream_t st, int task_changed) {
 #if REX_EN_WALKER2D
-  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, h->dev, mask, bit,
-                     (h->variant && task_changed) ? 1 : 0);
+  const bool auto_mask = mask == h->dev.done;   // the auto-reset path: the reset launch replaced the done bit by the pending bit
+  hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, h->dev, mask, auto_mask ? DERIVE_PENDING_BIT : bit,
+                     (h->variant && task_changed) ? 1 : 0, auto_mask ? 1 : 0);
   HIP_TRY(hipGetLastError());
 #endif
   return REX_OK;
@@ -932,13 +939,14 @@ static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, 
     case REX_CARTPOLE: hipLaunchKernelGGL(cartpole_reset_kernel, g, b, 0, st, h->dev, h->dr, resample, reset_state, mask, bit, obs); break;
 #endif
 #if REX_EN_HOPPER
-    case REX_HOPPER: hipLaunchKernelGGL(planar_reset_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_HOPPER: hipLaunchKernelGGL(planar_reset_kernel<HopperSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs, 0); break;
 #endif
 #if REX_EN_HALFCHEETAH
-    case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_reset_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_HALFCHEETAH: hipLaunchKernelGGL(planar_reset_kernel<HalfCheetahSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs, 0); break;
 #endif
 #if REX_EN_WALKER2D
-    case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
+    case REX_WALKER2D: hipLaunchKernelGGL(planar_reset_kernel<Walker2dSpec>, g, b, 0, st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs,
+                                          (resample && mask == h->dev.done) ? DERIVE_PENDING_BIT : 0); break;
 #endif
 #if REX_EN_HUMANOID
     case REX_HUMANOID: hipLaunchKernelGGL(humanoid_reset_kernel, g, b, hum_lds_bytes(h), st, h->dev, h->flags, h->dr, resample, reset_state, mask, bit, obs); break;
@@ -1061,7 +1069,7 @@ extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const 
   if (h->kind == REX_WALKER2D) {             // geometry of the caller's xi lengths (what set_task's build_model does)
     if (!h->rp_rows) HIP_TRY(hipMalloc(&h->rp_rows, sizeof(float) * kWalkerCompact * B));
     dev.geom = h->rp_rows;
-    hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, (const unsigned char*)nullptr, 0, h->variant ? 1 : 0);
+    hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, (const unsigned char*)nullptr, 0, h->variant ? 1 : 0, 0);
     HIP_TRY(hipGetLastError());
   }
 #endif
