@@ -26,6 +26,7 @@
 #include "../../include/rex.h"
 #include "planar_model.hpp"
 #include "humanoid_model.hpp"
+#include "humanoid_pair.hpp"
 
 using namespace rex;
 
@@ -566,6 +567,122 @@ __global__ void __launch_bounds__(64) humanoid_step_kernel(DevState s, StepFlags
   if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
 }
 
+// ---- the step kernel over TWO LANES PER ENVIRONMENT (humanoid_pair.hpp): lanes 2e / 2e + 1 of a 64-lane block hold env e, the right
+// lane the trunk + right leg / arm, the left lane the trunk (replicated) + left leg / arm; 32 envs per wave, every lane active.
+struct DevPair {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __device__ __forceinline__ int side() const { return (int)(threadIdx.x & 1u); }
+  __device__ __forceinline__ float xchg(float x) const { return pair_xchg(x); }
+  __device__ __forceinline__ unsigned xchg(unsigned x) const { return pair_xchg(x); }
+  __device__ __forceinline__ bool any(bool b) const { return REX_WAVE_ANY(b); }
+  __device__ __forceinline__ float* col() const { return hum::hum_lds + (threadIdx.x >> 1) * hum::pr::PAIR_WORDS; }
+  // LDS hand-over between the two lanes of a pair: same wave, LDS operations of a wave execute in order, so only the COMPILER has
+  // to be kept from moving a read of the partner's words above the partner's (= this instruction's) write
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#else   // (the host pass only parses the kernel body)
+  __device__ int side() const { return 0; }
+  __device__ float xchg(float x) const { return x; }
+  __device__ unsigned xchg(unsigned x) const { return x; }
+  __device__ bool any(bool b) const { return b; }
+  __device__ float* col() const { return nullptr; }
+  __device__ void sync() const {}
+#endif
+};
+
+__global__ void __launch_bounds__(64) humanoid_pair_step_kernel(DevState s, StepFlags fl, const float* __restrict__ action,
+                                                                float* __restrict__ obs, float* __restrict__ reward,
+                                                                unsigned char* __restrict__ done_out, unsigned char* __restrict__ trunc_out,
+                                                                float* __restrict__ term_obs) {
+  namespace pr = hum::pr;
+  const unsigned lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned i = lane >> 1;
+  if (i >= s.B) return;   // (both lanes of a pair leave together)
+  const bool left = (lane & 1u) != 0u;
+  const size_t B = (size_t)s.B;
+  const DevPair p;
+  // set_task (random_humanoid.py:156-158): body_mass[1:] = xi[:13]; dof_damping[6:] = xi[13:] -- this lane's 8 bodies / 16 dofs
+  pr::PLane<float> L;
+  static_for<0, pr::LB>([&](auto BB) { constexpr int lb = BB; L.mass[lb] = (s.xi + (size_t)((left ? pr::gbL(lb) : pr::gbR(lb)) - 1) * B)[i]; });
+  static_for<0, pr::LD>([&](auto DD) { constexpr int ld = DD;
+    if constexpr (ld < 6) L.damping[ld] = 0.0f; else L.damping[ld] = (s.xi + (size_t)(13 + (left ? pr::gdL(ld) : pr::gdR(ld)) - 6) * B)[i]; });
+  float ql[pr::LQ], vl[pr::LD], cl[pr::LU], xp[pr::LB];
+  static_for<0, 7>([&](auto KK) { constexpr int k = KK; ql[k] = (s.qpos + (size_t)k * B)[i]; });
+  static_for<6, pr::LD>([&](auto DD) { constexpr int ld = DD; ql[ld + 1] = (s.qpos + (size_t)((left ? pr::gdL(ld) : pr::gdR(ld)) + 1) * B)[i]; });
+  static_for<0, pr::LD>([&](auto DD) { constexpr int ld = DD; vl[ld] = (s.qvel + (size_t)(left ? pr::gdL(ld) : pr::gdR(ld)) * B)[i]; });
+  static_for<6, pr::LD>([&](auto DD) { constexpr int ld = DD;     // data.ctrl holds the raw action (:167); motor u drives dof kActDof[u]
+    constexpr int uR = ld == 6 ? 1 : ld == 7 ? 0 : ld == 8 ? 2 : ld < 13 ? 3 + (ld - 9) : 11 + (ld - 13);
+    constexpr int uL = ld < 9 ? uR : ld < 13 ? 7 + (ld - 9) : 14 + (ld - 13);
+    cl[ld - 6] = (action + (size_t)(left ? uL : uR) * B)[i]; });
+  static_for<0, pr::LB>([&](auto BB) { constexpr int lb = BB; xp[lb] = (s.aux + (size_t)(left ? pr::gbL(lb) : pr::gbR(lb)) * B)[i]; });
+  float asq_side = 0.0f, asq = 0.0f;
+  static_for<0, 3>([&](auto KK) { asq += cl[KK] * cl[KK]; });
+  static_for<3, pr::LU>([&](auto KK) { asq_side += cl[KK] * cl[KK]; });
+  asq += pr::psum(p, asq_side);
+  pr::PKin<float> kn; pr::PScratch<float> sc; pr::PObs<float> park;
+#if defined(REX_KTIME)
+  for (int k = 0; k < HT_SLOTS; k++) kn.tacc[k] = 0;
+#endif
+  const int t = s.t[i] + 1;
+#if defined(REX_WAVETIME)
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
+  float r, terms[4]; bool dn;
+  pr::env_step(p, c_hum, L, ql, vl, cl, asq, xp, kn, sc, park, r, dn, terms);
+#if defined(REX_WAVETIME)
+  if ((threadIdx.x & 63) == 0) g_wavetime[blockIdx.x & 8191] = __builtin_amdgcn_s_memtime() - tk0;
+#endif
+#if defined(REX_KTIME)
+  for (int k = 0; k < HT_SLOTS; k++) {   // one flush per wave and kernel: the wave maximum of every accumulator
+    unsigned long long v = kn.tacc[k];
+    for (int off = 32; off > 0; off >>= 1) { unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[8 + k], v);
+  }
+#endif
+  // observation (random_humanoid.py:193-204); noise only on the qpos / qvel slices: the 45 draws in row order, as one lane per env made them
+  float nz[45];
+  if (fl.noisy) {
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)s.episode[i] * EP_STRIDE + STEP_BASE + (unsigned long long)t * STEP_STRIDE, &st);
+    for (int k = 0; k < 45; k++) nz[k] = fl.noise_std * rocrand_normal(&st);
+  }
+  pr::emit_obs(p, ql, vl, park, [&](auto RR, auto RL, float val) {
+    constexpr int rr = RR, rl = RL;
+    if constexpr (rr < 45 && rl < 45) { if (fl.noisy) val += left ? nz[rl] : nz[rr]; }
+    const size_t row = left ? (size_t)rl : (size_t)rr;
+    (obs + row * B)[i] = val;
+    if (term_obs) (term_obs + row * B)[i] = val;
+  });
+  bool finite = true;
+  static_for<0, pr::LQ>([&](auto KK) { finite = finite && isfinite(ql[KK]); });
+  static_for<0, pr::LD>([&](auto KK) { finite = finite && isfinite(vl[KK]); });
+  finite = finite && (p.xchg(finite ? 1u : 0u) != 0u);
+  if (!finite) dn = true;                                           // a diverged lane ends its episode
+  if (fl.endless && finite) dn = false;
+  const bool trunc = fl.time_limit && t >= fl.max_steps && !dn && !fl.readonly;
+  const bool d = dn || trunc;
+  if (!fl.readonly) {   // (rex_replay: nothing of the handle is written, its counters included)
+    static_for<9, pr::LD>([&](auto DD) { constexpr int ld = DD; const size_t g = left ? pr::gdL(ld) : pr::gdR(ld);
+      (s.qpos + (g + 1) * B)[i] = ql[ld + 1]; (s.qvel + g * B)[i] = vl[ld]; });
+    static_for<3, pr::LB>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(left ? pr::gbL(lb) : pr::gbR(lb)) * B)[i] = xp[lb]; });
+  }
+  if (left) return;
+  if (!fl.readonly) {
+    if (!finite) atomicAdd(s.counters + 0, 1ull);
+    if (kn.overflow) atomicAdd(s.counters + 3, 1ull);
+    s.t[i] = t;
+    static_for<0, 10>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = ql[k]; });
+    static_for<0, 9>([&](auto KK) { constexpr int k = KK; (s.qvel + (size_t)k * B)[i] = vl[k]; });
+    static_for<0, 3>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(lb + 1) * B)[i] = xp[lb]; });
+    s.aux[i] = 0.0f;                                                // world body
+    s.done[i] = d ? 2 : 0;
+  }
+  if (fl.info) for (int k = 0; k < 4; k++) (fl.info + k * B)[i] = terms[k];   // reward_linvel, _quadctrl, _alive, _impact (random_humanoid.py:182-187)
+  reward[i] = r; done_out[i] = d ? 1 : 0;
+  if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+}
+
 // reset_model (random_humanoid.py:219-234): init noise U(-.01,.01) on all of qpos (incl. the quaternion) and qvel,
 // set_state -> sim.forward() with the CURRENT task, THEN set_random_task (the cinert block of the
 // returned observation is computed with the previous episode's masses).
@@ -641,6 +758,7 @@ struct rex_env {
   float* d_chol = nullptr;      // MAX_XI*MAX_XI floats (fullgaussian Cholesky factor)
   int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
   int pair = 1;                 // planar chains: two lanes per env (REX_PAIR=0: one lane per env)
+  int hum_pair = 1;             // humanoid step: two lanes per env (humanoid_pair_step_kernel; REX_HUM_PAIR=0: one env per lane)
   // timing: event pool created by rex_enable_timing, used as a ring by rex_step (no allocation in the step path)
   int timing = 0;
   std::vector<hipEvent_t> ev0, ev1;
@@ -814,6 +932,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       if (!built) {
         hum::build_model(md);
         if (!hum::check_topology(md)) return set_err(REX_ERR_ARG, "humanoid: compile-time dof tree differs from the model tables");
+        if (!hum::pr::check_pair_model(md)) return set_err(REX_ERR_ARG, "humanoid: a side body carries an orientation offset (humanoid_pair.hpp assumes none)");
         hum::convert_model(md, mf); built = true;
       }
       { hum::Model<float> up = mf;   // diagnostics: REX_HUM_ITERS caps the PGS sweeps (timing experiments only)
@@ -845,6 +964,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_CORR")) h->sp.corr = atoi(getenv("REX_CORR"));
   if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
   if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
+  if (getenv("REX_HUM_PAIR")) h->hum_pair = atoi(getenv("REX_HUM_PAIR")) ? 1 : 0;
   if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
@@ -984,6 +1104,20 @@ static void launch_planar_step(rex_env* h, const DevState& dev, const StepFlags&
   }
 }
 
+#if REX_EN_HUMANOID
+static void launch_humanoid_step(rex_env* h, const DevState& dev, const StepFlags& flags, const float* action, float* obs_out, float* reward_out,
+                                 uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out, hipStream_t st) {
+  if (h->hum_pair) {   // 2 B lanes in 64-lane blocks: 32 envs per wave, one LDS column per env
+    const unsigned blocks = (unsigned)((2 * h->B + 63) / 64);
+    hipLaunchKernelGGL(humanoid_pair_step_kernel, dim3(blocks), dim3(64), sizeof(float) * hum::pr::PAIR_WORDS * 32, st, dev, flags, action, obs_out,
+                       reward_out, done_out, truncated_out, terminal_obs_out);
+  } else {
+    hipLaunchKernelGGL(humanoid_step_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, flags, action, obs_out, reward_out,
+                       done_out, truncated_out, terminal_obs_out);
+  }
+}
+#endif
+
 extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
                         uint8_t* truncated_out, float* terminal_obs_out, void* stream) {
   if (!h) return set_err(REX_ERR_ARG, "null handle");
@@ -1019,7 +1153,7 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
 #endif
 #if REX_EN_HUMANOID
     case REX_HUMANOID:
-      hipLaunchKernelGGL(humanoid_step_kernel, g, b, hum_lds_bytes(h), st, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out); break;
+      launch_humanoid_step(h, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, st); break;
 #endif
   }
   if (timed) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }
@@ -1093,8 +1227,7 @@ extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const 
       if (!h->rp_rows) HIP_TRY(hipMalloc(&h->rp_rows, sizeof(float) * hum::NBODY * B));
       dev.aux = h->rp_rows;
       hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, (float*)nullptr);
-      hipLaunchKernelGGL(humanoid_step_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, flags, action, obs_out, reward_out, done_out,
-                         (unsigned char*)nullptr, (float*)nullptr);
+      launch_humanoid_step(h, dev, flags, action, obs_out, reward_out, done_out, nullptr, nullptr, st);
       break;
 #endif
     default: break;
