@@ -38,7 +38,7 @@ BYTES_PER_KIND = {"hopper": 173, "walker2d": 293, "halfcheetah": 273, "cartpole"
 # the names rocprofv3 / profiles/hbm_traffic.json show for the launched instantiation (PAIR = two lanes per env)
 KERNEL_OF_KIND = {"hopper": "planar_step_kernel<rex::HopperSpec, true>", "walker2d": "planar_step_kernel<rex::Walker2dSpec, true>",
                   "halfcheetah": "planar_step_kernel<rex::HalfCheetahSpec, true>", "cartpole": "cartpole_step_kernel",
-                  "humanoid": "humanoid_step_kernel"}
+                  "humanoid": "humanoid_pair_step_kernel"}
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 

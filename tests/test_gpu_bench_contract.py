@@ -39,7 +39,7 @@ def test_headline_line_contract():
 def test_humanoid_line():
     d = _run("--env", "RandomHumanoid-v0", "--steps", "12", "--warmup", "3", "--batch", "2048", "--no-cpu-baseline")
     assert "RandomHumanoid-v0" in d["config"]["workload"] and d["value"] > 1e5
-    assert d["roofline"]["bytes_per_env_step"] == 2073 and d["roofline"]["kernel"] == "humanoid_step_kernel"
+    assert d["roofline"]["bytes_per_env_step"] == 2073 and d["roofline"]["kernel"] == "humanoid_pair_step_kernel"
     assert d["nonfinite_lanes"] == 0
 
 

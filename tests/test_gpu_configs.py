@@ -237,7 +237,7 @@ def test_bench_gpus_n_starts_its_own_ranks():
 
 @pytest.mark.parametrize("cfg,eid,B,kernel,nbytes", [
     ("C2", "RandomHopper-v0", 4096, "HopperSpec", 173), ("C3", "RandomHalfCheetahNoisy-v0", 16384, "HalfCheetahSpec", 273),
-    ("C4", "RandomWalker2d-v0", 8192, "Walker2dSpec", 293), ("C5", "RandomHumanoid-v0", 32768, "humanoid_step_kernel", 2073)])
+    ("C4", "RandomWalker2d-v0", 8192, "Walker2dSpec", 293), ("C5", "RandomHumanoid-v0", 32768, "humanoid_pair_step_kernel", 2073)])
 def test_bench_config_lines(cfg, eid, B, kernel, nbytes):
     """`bench.py --config C2..C5`: SURVEY 8(d)'s inputs, each line with the roofline of its own kernel and (C2) the CPU leg
     on the GPU leg's settled states."""
