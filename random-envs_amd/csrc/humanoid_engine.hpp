@@ -1219,12 +1219,20 @@ REX_HD void env_step(const Model<T>& m, const Lane<T>& L, T* qpos, T* qvel, cons
   emit_obs(qpos, qvel, s, obs);
 }
 
-// observation right after set_state / reset: sim.forward() at the given state (jinja_mujoco_env.py:146-154)
+// observation right after set_state / reset: sim.forward() at the given state (jinja_mujoco_env.py:146-154).  Of that forward
+// the observation reads cinert, cvel, xipos and qfrc_actuator only (random_humanoid.py:193-204; data.ctrl is zero after
+// sim.reset(), so qfrc_actuator = 0): kinematics -> com -> velocities, in forward()'s order and arithmetic -- no collision, no
+// mass matrix, no solver (the reset launch of every step used to pay a whole evaluation for them).
 template <class T, class ObsSink>
 REX_HD void env_reset_obs(const Model<T>& m, const Lane<T>& L, const T* qpos, const T* qvel, T* xipos_x, Kin<T>& K, Scratch<T>& s, ObsSink&& obs) {
-  T ctrl[NU], acc[NV];
-  for (int u = 0; u < NU; u++) ctrl[u] = 0;                        // sim.reset() zeroes data.ctrl
-  forward(m, L, qpos, qvel, ctrl, K, s, acc);
+  K.overflow = 0; K.ncon = 0; K.nefc = 0;
+  Smooth<T> S;
+  kinematics(m, qpos, S, s);
+  com_pos(m, L, S, s);
+  T qfrc_bias[NV];
+  com_vel_rne(m, L, qvel, S, qfrc_bias);
+  static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) s.obs_cinert[b][k] = S.cinert[b][k]; for (int k = 0; k < 6; k++) s.obs_cvel[b][k] = S.cvel[b][k]; s.obs_xipos_x[b] = S.xipos[b][0]; });
+  static_for<0, NV>([&](auto II) { s.obs_qfrc_actuator[II] = T(0); });
   static_for<0, NBODY>([&](auto BB) { constexpr int b = BB; xipos_x[b] = s.obs_xipos_x[b]; });
   emit_obs(qpos, qvel, s, obs);
 }
