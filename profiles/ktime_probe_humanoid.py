@@ -25,4 +25,10 @@ n = o[11]
 print("wave-evaluations: %d; per evaluation: %.1f collide_pair calls, %.1f add_contact calls, %.1f sweeps (wave max), rows (wave max) %.1f" %
       (n, o[12] / n, o[13] / n, o[14] / n, o[15] / n))
 for i, nm in enumerate(names): print("  %-34s %9.0f ticks/eval  %5.1f%%" % (nm, o[i] / n, 100.0 * o[i] / o[10]))
+lv = list(out)[24:]
+tot = sum(lv[8:16]) or 1
+print("sweep levels (rows <= 4, 8, 10, 12, 14, 16, 18, 21): share of wave-evaluations with rows / cycles per evaluation in the sweeps / in the A build / share of all sweep cycles")
+for k, nc in enumerate((4, 8, 10, 12, 14, 16, 18, 21)):
+    if lv[k]: print("  NC %2d: %5.1f%%  %8.0f  %8.0f  %5.1f%%" % (nc, 100.0 * lv[k] / sum(lv[0:8]), lv[16 + k] / lv[k], lv[32 + k] / lv[k], 100.0 * lv[16 + k] / sum(lv[16:24])))
+print("wave-evaluations by largest row count 1..21:", " ".join("%d:%.1f%%" % (k, 100.0 * lv[48 + k] / max(sum(lv[48:72]), 1)) for k in range(1, 22)))
 env.close()

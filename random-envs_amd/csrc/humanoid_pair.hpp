@@ -24,6 +24,9 @@
 #pragma once
 #include "humanoid_engine.hpp"
 
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+namespace rex { extern __device__ unsigned long long g_ktime[24 + 72]; }   // [24 + lvl]: wave-evaluations per sweep level, [40 + lvl]: their sweep cycles
+#endif
 namespace rex {
 namespace hum {
 namespace pr {
@@ -654,67 +657,6 @@ REX_HD int solve_pgs(const P& p, const Model<T>& m, const PFactor<T>& F, const P
   return it;
 }
 
-// ---- pgs_sweeps_sq over the pair (device, fp32): the residuals are split -- lane 0 keeps res[0 .. NP/2), lane 1 res[NP/2 .. NP) -- so
-// an update of f_i reads and pushes only HALF of row i per lane; the lane that owns res_i computes the new force, the partner
-// gets it with one DPP move.  Every residual sees the same sequence of multiply-adds as in the replicated form, so the result
-// is bit-identical to pgs_sweeps_sq (which the host harness and the 4-row level keep using).
-#if defined(__HIP_DEVICE_COMPILE__)
-template <int NC, class P>
-__device__ __forceinline__ int pgs_sweeps_sq_pair(const P& p, const Model<float>& m, const float* col, float (&f)[DUAL_NMAX]) {
-  constexpr int NP = sq_stride(NC), BOFF = NP * NP, DOFF = BOFF + NP, NH = NP / 2;
-  static_assert(NH % 2 == 0 && NC <= DUAL_NMAX, "half rows are read as 8-byte words");
-  typedef pgs_v2f v2f;
-  const bool hi = p.side() != 0;
-  const float* const colh = col + (hi ? NH : 0);       // this lane's half of every row (8-byte aligned: NH is even)
-  const float scale = 1.0f / (m.meaninertia * float(NV));
-  v2f rp[NH / 2]; float fv[NC];
-  static_for<0, NH / 2>([&](auto QQ) { constexpr int q = QQ; rp[q] = *(const v2f*)(colh + BOFF + 2 * q); });
-  static_for<0, NC>([&](auto II) { fv[II] = 0.0f; });
-  v2f buf[NH / 2]; float dnext;
-  auto load_row = [&](auto II, v2f (&a)[NH / 2], float& d) {
-    constexpr int i = II;
-    static_for<0, NH / 2>([&](auto QQ) { constexpr int q = QQ; a[q] = *(const v2f*)(colh + i * NP + 2 * q); });
-    d = col[DOFF + i];
-  };
-  load_row(IC<0>{}, buf, dnext);
-  int it = 0;
-  for (; it < m.iterations; it++) {
-    float improvement = 0;
-    static_for<0, NC>([&](auto II) {
-      constexpr int i = II, nxt = (i + 1) % NC;
-      constexpr bool ownhi = i >= NH;                  // the lane that holds res_i (and A_ii in its half of row i)
-      constexpr int il = i - (ownhi ? NH : 0);
-      v2f a[NH / 2]; const float di = dnext;
-      static_for<0, NH / 2>([&](auto QQ) { a[QQ] = buf[QQ]; });
-      load_row(IC<nxt>{}, buf, dnext);                 // next row in flight while this one is consumed
-      const float res = (il & 1) ? rp[il / 2].y : rp[il / 2].x;
-      const float old = fv[i], nf_mine = __builtin_fmaxf(0.0f, old - res * di);
-      const float nf_other = p.xchg(nf_mine);
-      const bool owner = hi == ownhi;
-      const float nf = owner ? nf_mine : nf_other, df = nf - old;
-      fv[i] = nf;
-      const float aii = (il & 1) ? a[il / 2].y : a[il / 2].x;
-      const float term = df * (0.5f * df * aii + res);
-      improvement -= owner ? term : 0.0f;
-      const v2f dfp = {df, df};
-      static_for<0, NH / 2>([&](auto QQ) { constexpr int q = QQ; rp[q] = __builtin_elementwise_fma(a[q], dfp, rp[q]); });
-    });
-    improvement += p.xchg(improvement);                // (commutative: the same bits in both lanes)
-    if (improvement * scale < m.tolerance) { it++; break; }
-  }
-  static_for<0, NC>([&](auto II) { f[II] = fv[II]; });
-  return it;
-}
-#endif
-template <int NC, class T, class P>
-REX_HD int pgs_sweeps_sq_split(const P& p, const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK) && !defined(REX_NO_SPLIT_SWEEPS)
-  if constexpr (sizeof(T) == 4) return pgs_sweeps_sq_pair<NC>(p, m, col, f);
-  else
-#endif
-  return pgs_sweeps_sq<NC>(m, col, f);
-}
-
 // ---- the dual PGS (A = J M^-1 J^T + R in the env's LDS column; humanoid_engine.hpp::solve_pgs_dual) with the row algebra
 // over the pair: every lane back-substitutes its own 16 columns, dot products are partial sums exchanged once ------------------
 template <class T, class P>
@@ -770,15 +712,20 @@ REX_HD int solve_pgs_dual(const P& p, const Model<T>& m, const PFactor<T>& F, PK
   static_for<0, DUAL_NMAX>([&](auto II) { f[II] = T(0); });
   switch (lvl) {
     case 0: it = pgs_sweeps_sq<4>(m, col, f); break;
-    case 1: it = pgs_sweeps_sq_split<8>(p, m, col, f); break;
-    case 2: it = pgs_sweeps_sq_split<10>(p, m, col, f); break;
-    case 3: it = pgs_sweeps_sq_split<12>(p, m, col, f); break;
-    case 4: it = pgs_sweeps_sq_split<14>(p, m, col, f); break;
-    case 5: it = pgs_sweeps_sq_split<16>(p, m, col, f); break;
+    case 1: it = pgs_sweeps_sq<8>(m, col, f); break;
+    case 2: it = pgs_sweeps_sq<10>(m, col, f); break;
+    case 3: it = pgs_sweeps_sq<12>(m, col, f); break;
+    case 4: it = pgs_sweeps_sq<14>(m, col, f); break;
+    case 5: it = pgs_sweeps_sq<16>(m, col, f); break;
     case 6: it = pgs_sweeps<18>(m, col, n, f); break;
     default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
   }
   REX_HSTAMP(p2); REX_HACC(K, HT_SWEEPS, p1, p2); REX_HCNT(K, HC_SWEEPS, it);
+#if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
+  { int nm = n; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(nm, off); nm = o > nm ? o : nm; }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_ktime[24 + lvl], 1ull); atomicAdd(&g_ktime[40 + lvl], p2 - p1); atomicAdd(&g_ktime[56 + lvl], p1 - p0);
+                                   atomicAdd(&g_ktime[72 + (nm < 23 ? nm : 23)], 1ull); } }   // [72 + n]: wave-evaluations by their largest row count
+#endif
   T x[LD];
   for (int k = 0; k < LD; k++) x[k] = 0;
   static_for<0, DUAL_NMAX / 3>([&](auto CC) {

@@ -925,7 +925,12 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       const bool big_ok = nl <= 2 && nl + ns >= 1 &&
                           (PAIR ? (__builtin_popcount(tm & EVEN) <= 1 && __builtin_popcount(tm & ODD) <= 1) : ns <= 2);
       // wave-uniform: the multi-group form only when some lane's set changed in more than one group (0.25 % of the solves)
-      const bool use_big = corr >= 2 && REX_WAVE_ANY(pending && big_ok && !small_ok);
+#if defined(__HIP_DEVICE_COMPILE__)
+      constexpr bool BIG = PAIR;   // device, one lane per env (REX_PAIR=0, an A/B knob): the one-group form only -- six solves in one lane spill
+#else
+      constexpr bool BIG = true;   // host builds validate the multi-group algebra in the one-lane form
+#endif
+      const bool use_big = BIG && corr >= 2 && REX_WAVE_ANY(pending && big_ok && !small_ok);
       bool can = pending && (use_big ? big_ok : small_ok);
       if (!REX_WAVE_ANY(can)) break;
       {
@@ -950,7 +955,7 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           });
         };
         auto dotv = [&](const T (&x)[S::NV], const T (&y)[S::NV]) { T r = T(0); static_for<0, S::NV>([&](auto II) { r += x[II] * y[II]; }); return r; };
-        if (!use_big) {
+        if (!BIG || !use_big) {
           // ---- one group: a joint limit (its unit column rides in Ut) or one slot: 2 x 2
           T Ut[S::NV], Un[S::NV], Ctt, Ctn, Cnn, wt, wn;
           slot_group(sel1, Ut, Un, Ctt, Ctn, Cnn, wt, wn);
@@ -1201,9 +1206,12 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
 #if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
   if constexpr (S::NSELF == 0) { if (mode == 1) REX_COUNT(selfpath, 1); }   // (slot "selfpath" of a chain without self pairs: general-path solves)
 #endif
+#if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (S::NSELF == 0) { if (mode == 1) REX_COUNT(selfpath, 1); }   // (slot "selfpath" of a chain without self pairs: general-path solves)
+#endif
   REX_MARK("forward_end");
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-  gstats().trace[gstats().ntrace++ & 63] = st.iters;
+  gstats().trace[gstats().ntrace++ & 63] = st.iters + 100 * mode;
 #endif
   REX_PSTAMP(p_5, qacc[0] + qacc[S::NV - 1]);
   REX_PACC(0, p_0, p_1); REX_PACC(1, p_1, p_2); REX_PACC(2, p_2, p_3); REX_PACC(3, p_3, p_4); REX_PACC(4, p_4, p_5);

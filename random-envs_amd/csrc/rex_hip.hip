@@ -279,6 +279,13 @@ __device__ __forceinline__ void write_obs(const float (&q)[S::NV], const float (
 template <class S>
 __device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepFlags& fl, const DRParams& dr, int resample,
                                                   int reset_state, unsigned i, float* __restrict__ obs);
+// walker2d: the per-env model constants of lane i from its xi lengths (what build_model() does inside
+// RandomWalker2dEnv.set_task, random_walker2d.py:106-113)
+__device__ __forceinline__ void walker_derive_lane(const DevState& s, unsigned i, int refresh_frozen_masses);
+// `resample` argument of the step kernel: bit 0 = set_random_task at reset, bit 1 = walker2d: re-derive the lane's geometry from its
+// new xi lengths right there (the auto-reset under DR used to cost a reset launch and a derive launch behind every step),
+// bit 2 = the Unmodeled id's frozen masses follow the new lengths
+constexpr int RS_RESAMPLE = 1, RS_DERIVE = 2, RS_REFRESH = 4;
 
 // Register budget of the planar step kernel: waves per SIMD the allocator must leave room for (512 registers per lane and
 // SIMD: 1 wave -> 512, 2 -> 256, 3 -> 168, 4 -> 128).  A lone wave issues one VALU instruction per 4 cycles, the SIMD one
@@ -380,7 +387,10 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
 #if defined(REX_WAVETIME)
   const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
-  if (fused_reset && d) planar_reset_lane<S>(s, fl, dr, resample, 1, io, obs);
+  if (fused_reset && d) {
+    planar_reset_lane<S>(s, fl, dr, resample & RS_RESAMPLE, 1, io, obs);
+    if constexpr (S::KIND == 3 && PAIR) { if (resample & RS_DERIVE) walker_derive_lane(s, io, (resample & RS_REFRESH) ? 1 : 0); }   // (one lane per env, REX_PAIR=0: the derive launch stays -- inlined there it spills)
+  }
 #if defined(REX_WAVETIME)
   if ((threadIdx.x & 63) == 0) { g_waveinfo[blockIdx.x & 8191][1] += __builtin_amdgcn_s_memtime() - tr0; }   // slot 1 ("iters", unused): cycles in the fused reset
   if ((threadIdx.x & 63) == 0) { unsigned long long* ph = g_wavephase[blockIdx.x & 8191]; ph[0] = tk0 - tp0; ph[1] = tk1 - tk0; ph[2] = tr0 - tk1; ph[3] = __builtin_amdgcn_s_memtime() - tr0; }
@@ -450,6 +460,10 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
   if (i >= s.B) return;
   if (mask && !(mask[i] & mask_bit)) return;
   if (clear_pending) s.done[i] = 0;   // (mask is s.done: the pending bit planar_reset_kernel left)
+  walker_derive_lane(s, i, refresh_frozen_masses);
+}
+__device__ __forceinline__ void walker_derive_lane(const DevState& s, unsigned i, int refresh_frozen_masses) {
+  using S = Walker2dSpec;
   double size[4];
   for (int k = 0; k < 4; k++) size[k] = (double)s.xi[(long long)(7 + k) * s.B + i];
   PlanarGeom<double, S> G; SolParams<double> sp; double nominal[S::NB];
@@ -461,6 +475,8 @@ __global__ void __launch_bounds__(64) walker_derive_kernel(DevState s, const uns
   // masses 1..3 become the geometry-derived ones of the new lengths (random_walker2d_unmodeled.py:109-116)
   if (refresh_frozen_masses) for (int b = 0; b < 3; b++) (s.xi + (size_t)b * s.B)[i] = (float)nominal[b];
 }
+#else
+__device__ __forceinline__ void walker_derive_lane(const DevState&, unsigned, int) {}
 
 #endif
 
@@ -638,6 +654,9 @@ __global__ void __launch_bounds__(64) humanoid_pair_step_kernel(DevState s, Step
     unsigned long long v = kn.tacc[k];
     for (int off = 32; off > 0; off >>= 1) { unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_ktime[8 + k], v);
+#if defined(REX_WAVETIME)
+    if ((threadIdx.x & 63) == 0 && k < 16) g_wavehum[blockIdx.x & 1023][k] = v;
+#endif
   }
 #endif
   // observation (random_humanoid.py:193-204); noise only on the qpos / qvel slices: the 45 draws in row order, as one lane per env made them
@@ -1126,9 +1145,11 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   HIP_TRY(hipSetDevice(h->device));
   const dim3 g(grid_for(h)), b(lanes_of(h));
   const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
-  // planar envs reset finished lanes inside the step kernel; walker2d with DR needs the separate derive launch
-  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH ||
-                                      (h->kind == REX_WALKER2D && !(resample_on_reset && h->dr.type != REX_DR_NONE)))) ? 1 : 0;
+  // planar envs reset finished lanes inside the step kernel (walker2d under DR re-derives the lane's geometry there as well)
+  const bool walker_dr = h->kind == REX_WALKER2D && resample_on_reset && h->dr.type != REX_DR_NONE;
+  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || h->pair)))) ? 1 : 0;
+  int rs = resample_on_reset ? RS_RESAMPLE : 0;
+  if (walker_dr && h->pair) rs |= RS_DERIVE | (h->variant ? RS_REFRESH : 0);
   // every `timing`-th launch is bracketed by two events of the pool rex_enable_timing created (ring): the two event packets
   // cost ~8 us of stream time per launch, 9 % of a hopper step, so a throughput run samples (bench.py: every 8th launch)
   const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;
@@ -1141,15 +1162,15 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
 #endif
 #if REX_EN_HOPPER
     case REX_HOPPER:
-      launch_planar_step<HopperSpec>(h, h->dev, h->flags, h->g_hopper, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
+      launch_planar_step<HopperSpec>(h, h->dev, h->flags, h->g_hopper, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, rs, st); break;
 #endif
 #if REX_EN_HALFCHEETAH
     case REX_HALFCHEETAH:
-      launch_planar_step<HalfCheetahSpec>(h, h->dev, h->flags, h->g_cheetah, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
+      launch_planar_step<HalfCheetahSpec>(h, h->dev, h->flags, h->g_cheetah, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, rs, st); break;
 #endif
 #if REX_EN_WALKER2D
     case REX_WALKER2D:
-      launch_planar_step<Walker2dSpec>(h, h->dev, h->flags, h->g_walker, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, resample_on_reset, st); break;
+      launch_planar_step<Walker2dSpec>(h, h->dev, h->flags, h->g_walker, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, fused, rs, st); break;
 #endif
 #if REX_EN_HUMANOID
     case REX_HUMANOID:

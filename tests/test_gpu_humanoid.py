@@ -234,3 +234,37 @@ def test_pile_up_states_all_solver_paths(torch_mod):
     assert np.median(ev[ok]) < 1e-5, np.median(ev[ok])
     assert_lanes_explained(ev[ok], (sens["qvel"] / vs)[ok], 1e-4, 5e-1, K=256.0, label="humanoid pile-ups |dqvel|rel")
     env.close()
+
+
+@pytest.mark.gpu
+def test_crouched_states_every_sweep_layout(torch_mod):
+    """Crouching / half-fallen humanoids: 1 .. 30 constraint rows per evaluation, so every layout of the dual matrix is used --
+    the square sizes, the packed triangle (17 .. 21 rows: both feet flat + joint limits) and the scratch-row fallback.  One env
+    step vs the oracle, every lane."""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_humanoid_step, oracle_sensitivity
+    from parity_util import assert_lanes_explained
+    from random_envs_amd.specs import SPECS
+    torch = torch_mod
+    n = 768; rng = np.random.RandomState(11)
+    nom = np.array(SPECS["humanoid"].nominal_task)
+    q = np.tile(np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float), (n, 1))
+    q[:, 7:] += rng.uniform(-0.9, 0.9, (n, 17)); q[:, 2] = rng.uniform(0.3, 1.3, n)
+    qq = np.array([1, 0, 0, 0]) + rng.uniform(-.5, .5, (n, 4)); q[:, 3:7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+    v = rng.uniform(-1, 1, (n, 23)); a = rng.uniform(-.4, .4, (n, 17)); xi = nom * rng.uniform(.9, 1.1, (n, 30))
+    q, v, a, xi = [x.astype(np.float32).astype(np.float64) for x in (q, v, a, xi)]
+    env = rex.make("RandomHumanoid-v0", batch=n, autoreset=False)
+    env.set_task(xi.astype(np.float32)); env.set_state(q, v)
+    env.step(torch.as_tensor(a, dtype=torch.float32))
+    ref = oracle_humanoid_step(q, v, a, xi)
+    _, vv = env.get_state()
+    vv = vv.cpu().numpy().astype(np.float64)
+    ok = np.isfinite(ref["qvel"]).all(1)
+    vs = 1 + np.abs(ref["qvel"]).max(1)
+    ev = np.abs(vv - ref["qvel"]).max(1) / vs
+    c = env.counters()
+    assert c["overflow"] == 0 and ok.sum() > n * 0.9, c
+    _, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_humanoid_step(q_, v_, a_, x_), [q, v, a, xi], ["qvel"], trials=2)
+    assert np.median(ev[ok]) < 1e-5, np.median(ev[ok])
+    assert_lanes_explained(ev[ok], (sens["qvel"] / vs)[ok], 1e-4, 5e-1, K=256.0, label="humanoid crouched states |dqvel|rel")
+    env.close()

@@ -86,3 +86,4 @@ def test_pile_ups_all_solver_paths(hp):
     assert out["overflow"].sum() == 0 and ok.sum() > n // 2
     assert (out["nrows"] > 21).sum() >= 3 and (out["nrows"] <= 16).sum() >= 1, np.sort(out["nrows"])
     assert ev[ok].max() < 1e-7, ev[ok].max()
+
