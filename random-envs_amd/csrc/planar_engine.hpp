@@ -900,11 +900,9 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       // becomes the next target -- its step is again taken from x1 with the factorisation of A, as long as the change A -> target
       // stays within the groups the 5 x 5 form holds.  An active-set iteration at ~500 instructions a round instead of ~850.
       unsigned g_lim = m_lim, g1 = m_e1, g2 = m_e2, g3 = m_e3;   // target set: initially the set at x1
-      T xb[S::NV];                                               // x1, the base point of every round
-      static_for<0, S::NV>([&](auto II) { xb[II] = qacc[II]; });
+      T xb[S::NV];                                               // x1, the base point of every round (copied only in waves that correct)
       bool pending = !lane_done && a == T(1) && corr != 0;
       T jt1[NC], jn1[NC];
-      for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k]; });   // J x1 (alpha = 1)
       const int rounds = corr >= 3 ? corr - 1 : 1;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -933,6 +931,10 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       const bool use_big = BIG && corr >= 2 && REX_WAVE_ANY(pending && big_ok && !small_ok);
       bool can = pending && (use_big ? big_ok : small_ok);
       if (!REX_WAVE_ANY(can)) break;
+      if (round == 0) {   // (behind the wave-uniform test: an iteration without a correction pays nothing for these)
+        static_for<0, S::NV>([&](auto II) { xb[II] = qacc[II]; });
+        for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k]; });   // J x1 (alpha = 1)
+      }
       {
         T dx[S::NV];
         // basis columns U = [j_t j_n] of the slot `sel` (one bit, or none), the change dC of its edge weights and w = the toggled

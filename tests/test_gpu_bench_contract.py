@@ -79,6 +79,23 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert "batch 2048 per GPU" in strong["config"]["workload"]
 
 
+def test_self_launched_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts the two ranks itself (children created before the parent
+    touches torch or the GPU), hands them RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and relays rank 0's line -- `n_gpus` is
+    the size of the process group that was actually formed."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "24",
+                          "--warmup", "4", "--batch", "4096", "--no-cpu-baseline", "--counter-every", "8"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env_clean)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8192
+    assert abs(d["value"] - 8192 * 24 / (d["ms_per_step"] * 24 / 1e3)) < 1e-6 * d["value"]
+    assert d["counter_reductions"] == 4
+
+
 def test_replay_workload_line():
     """bench.py --replay: ONE logged transition replayed under a fresh candidate xi per env and step (set_task +
     set_sim_state + step, device-resident, no auto-reset) -- the second massively parallel workload (SURVEY 8 f2,
