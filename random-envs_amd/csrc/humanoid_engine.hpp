@@ -10,6 +10,7 @@
 // Host + device code (REX_HD): tests compile it for the CPU in fp64 / fp32.
 #pragma once
 #include <math.h>
+#include <type_traits>
 
 #include "planar_spec.hpp"   // REX_HD
 
@@ -832,6 +833,10 @@ REX_HD void pin_all(T (&a)[NP]) { if constexpr (Q < NP) { REX_PIN4(a[Q], a[Q + 1
 // live in registers and every index is a compile-time constant: a row update is one batch of LDS reads at fixed offsets
 // (no address arithmetic, no LDS write) followed by four short FMA chains.  Rows beyond the largest row count of the wave
 // are skipped; padding inside the range is zero, which makes its update a no-op.
+#ifndef REX_PGS_CHECK
+#define REX_PGS_CHECK 10
+#endif
+constexpr int PGS_CHECK = REX_PGS_CHECK;   // the device sweeps evaluate the stopping criterion every PGS_CHECK-th sweep (pgs_sweeps_sq)
 template <int NC, int I, class T>
 REX_HD void pgs_load_row(const T* col, T (&a)[(NC + 3) / 4 * 4 + 2]) {   // row I of the packed A, then b_I and 1 / A_II
   constexpr int NP = (NC + 3) / 4 * 4;
@@ -854,8 +859,8 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
   T buf[NP + 2];
   pgs_load_row<NC, 0>(col, buf);
   int it = 0;
-  for (; it < m.iterations; it++) {
-    T improvement = 0;
+  T improvement = 0;
+  auto sweep = [&](auto CHECK) {
     static_for<0, NC>([&](auto II) {
       constexpr int i = II, nxt = (i + 1) % NC;
       T a[NP + 2];
@@ -887,9 +892,24 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
       }
       const T old = f[i], nf = hmax(T(0), old - res * a[NP + 1]), df = nf - old;
       f[i] = nf;
-      improvement -= df * (T(0.5) * df * a[i] + res);   // cost decrease of this update ([3P] mj_solPGS), three instructions
+      if constexpr (decltype(CHECK)::value) improvement -= df * (T(0.5) * df * a[i] + res);   // cost decrease of this update ([3P] mj_solPGS), three instructions
     });
-    if (improvement * scale < m.tolerance) { it++; break; }
+  };
+  // the stopping criterion in every K-th sweep only on the device (pgs_sweeps_sq has the argument); every sweep on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int K = sizeof(T) == 4 ? PGS_CHECK : 1;
+#else
+  constexpr int K = 1;
+#endif
+  while (it < m.iterations) {
+    int nun = m.iterations - 1 - it; nun = nun < K - 1 ? nun : K - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int u = 0; u < nun; u++) { sweep(std::false_type{}); it++; }
+    improvement = 0;
+    sweep(std::true_type{}); it++;
+    if (improvement * scale < m.tolerance) break;
   }
   return it;
 }
@@ -928,8 +948,16 @@ REX_HD int pgs_sweeps_sq(const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
       d = col[DOFF + i];
     };
     load_row(IC<0>{}, buf, dnext);
-    for (; it < m.iterations; it++) {
-      float improvement = 0;
+    // [3P] mj_solPGS stops after the first sweep whose cost decrease falls under the tolerance.  Computing the decrease costs four
+    // of a row update's instructions and -- worse -- keeps the matrix from living in registers across the sweeps: without it a
+    // 12-row sweep is 125 instructions (6 v_pk_fma + fma, max, sub per row, no LDS read, no move) instead of 257.  A wave runs
+    // until its LAST lane stops (one that hits the 50-sweep cap in most waves), so the criterion is evaluated in every
+    // PGS_CHECK-th sweep only: a lane that would have stopped after sweep k stops after sweep PGS_CHECK * ceil(k / PGS_CHECK) <= 50
+    // instead -- up to PGS_CHECK - 1 more sweeps of a system already converged to the tolerance (1e-8 of the cost scale: far
+    // below fp32 rounding of the result; the unchecked sweeps cost half, so even those lanes do not pay), never more than
+    // MuJoCo's cap.  Humanoid step kernel 2.17 -> 1.99 ms (every 5th sweep, square sizes) -> 1.91 (packed sizes too) -> 1.86 (10th).
+    float improvement = 0;
+    auto sweep = [&](auto CHECK) {
       static_for<0, NC>([&](auto II) {
         constexpr int i = II, nxt = (i + 1) % NC;
         v4f a[NP / 4]; const float di = dnext;
@@ -938,8 +966,7 @@ REX_HD int pgs_sweeps_sq(const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
         const float res = (i & 1) ? rp[i / 2].y : rp[i / 2].x;
         const float old = fv[i], nf = __builtin_fmaxf(0.0f, old - res * di), df = nf - old;   // a NaN residual (non-finite state: the lane is flagged) gives 0
         fv[i] = nf;
-        const float aii = a[i / 4][i & 3];
-        improvement -= df * (0.5f * df * aii + res);
+        if constexpr (decltype(CHECK)::value) { const float aii = a[i / 4][i & 3]; improvement -= df * (0.5f * df * aii + res); }
         const v2f dfp = {df, df};
         static_for<0, NP / 4>([&](auto QQ) {
           constexpr int q = QQ;
@@ -947,7 +974,14 @@ REX_HD int pgs_sweeps_sq(const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
           rp[2 * q + 1] = __builtin_elementwise_fma(v2f{a[q].z, a[q].w}, dfp, rp[2 * q + 1]);
         });
       });
-      if (improvement * scale < m.tolerance) { it++; break; }
+    };
+    while (it < m.iterations) {
+      int nun = m.iterations - 1 - it; nun = nun < PGS_CHECK - 1 ? nun : PGS_CHECK - 1;
+#pragma unroll 1
+      for (int u = 0; u < nun; u++) { sweep(std::false_type{}); it++; }
+      improvement = 0;
+      sweep(std::true_type{}); it++;
+      if (improvement * scale < m.tolerance) break;
     }
     static_for<0, NC>([&](auto II) { f[II] = fv[II]; });
     return it;

@@ -592,7 +592,7 @@ extern __device__ unsigned long long g_evalphase[8192][16];
 
 struct SolveStats { int iters; bool capped; int mode; };   // mode: solver instantiation forward() entered (0 none, 1 general, 2 general + self rows, 3 feet-only straight-line)
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; long toggles[4][4]; int trace[64], ntrace; int ev[256][8], nev; };   // trace: Newton iterations of the last solves (scratch experiments)
+struct GlobalStats { long solves, iters, pass1, pass2, ls_evals, nocon, slots_active; long toggles[4][4]; int trace[64], ntrace; };   // trace: mode * 100 + Newton iterations of the last solves
 inline GlobalStats& gstats() { static GlobalStats g{}; return g; }
 #define REX_COUNT(field, n) (gstats().field += (n))
 #elif defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
@@ -896,172 +896,56 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     // set at x2 equals the set at x1 (then it is that set's exact minimiser); otherwise the regular iterations go on from x2.
     // PAIR: the lane that owns the toggled slot computes the step, the other one contributes zero; limits: the even lane.
     if constexpr (!BR && !SELF) {
-      // The correction may repeat (`corr` - 1 rounds at most): if the set at x2 is not the set x2 was computed for, that set
-      // becomes the next target -- its step is again taken from x1 with the factorisation of A, as long as the change A -> target
-      // stays within the groups the 5 x 5 form holds.  An active-set iteration at ~500 instructions a round instead of ~850.
-      unsigned g_lim = m_lim, g1 = m_e1, g2 = m_e2, g3 = m_e3;   // target set: initially the set at x1
-      T xb[S::NV];                                               // x1, the base point of every round (copied only in waves that correct)
-      bool pending = !lane_done && a == T(1) && corr != 0;
-      T jt1[NC], jn1[NC];
-      const int rounds = corr >= 3 ? corr - 1 : 1;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-      for (int round = 0; round < rounds; ++round) {
-      const unsigned t_lim = lim_on ^ g_lim, t1 = e1 ^ g1, t2 = e2 ^ g2, t3 = e3 ^ g3, tm = t1 | t2 | t3;
+      const unsigned t_lim = lim_on ^ m_lim, t1 = e1 ^ m_e1, t2 = e2 ^ m_e2, t3 = e3 ^ m_e3, tm = t1 | t2 | t3;
       const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-      if (round == 0 && !lane_done && a == T(1)) gstats().toggles[nl < 3 ? nl : 3][ns < 3 ? ns : 3]++;
-      if (round == 0) { int* e = gstats().ev[gstats().nev++ & 255]; e[0] = it; e[1] = nl; e[2] = ns; e[3] = a == T(1); e[4] = lane_done; e[5] = int(t_lim); e[6] = int(tm); e[7] = int(C.con_mask | (C.lim_mask << 16)); }
+      if (!lane_done && a == T(1)) gstats().toggles[nl < 3 ? nl : 3][ns < 3 ? ns : 3]++;
 #endif
-      // groups: G1 = the lane's first toggled slot, G2 = the second one.  PAIR: G1 = the toggled slot of the lane's OWN end, G2 is the
-      // partner's G1 (its columns are solved there and come over the pair); one lane per env: both are this lane's.
-      constexpr unsigned EVEN = SLOTS, ODD = SLOTS << 1;
-      const unsigned own = PAIR ? (tm & (par ? ODD : EVEN)) : tm;
-      const unsigned sel1 = own & (0u - own), rest = PAIR ? 0u : (own ^ sel1), sel2 = rest & (0u - rest);
-      const bool small_ok = (nl == 1 && ns == 0) || (nl == 0 && ns == 1);
-      const bool big_ok = nl <= 2 && nl + ns >= 1 &&
-                          (PAIR ? (__builtin_popcount(tm & EVEN) <= 1 && __builtin_popcount(tm & ODD) <= 1) : ns <= 2);
-      // wave-uniform: the multi-group form only when some lane's set changed in more than one group (0.25 % of the solves)
-#if defined(__HIP_DEVICE_COMPILE__)
-      constexpr bool BIG = PAIR;   // device, one lane per env (REX_PAIR=0, an A/B knob): the one-group form only -- six solves in one lane spill
-#else
-      constexpr bool BIG = true;   // host builds validate the multi-group algebra in the one-lane form
-#endif
-      const bool use_big = BIG && corr >= 2 && REX_WAVE_ANY(pending && big_ok && !small_ok);
-      bool can = pending && (use_big ? big_ok : small_ok);
-      if (!REX_WAVE_ANY(can)) break;
-      if (round == 0) {   // (behind the wave-uniform test: an iteration without a correction pays nothing for these)
-        static_for<0, S::NV>([&](auto II) { xb[II] = qacc[II]; });
-        for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k]; });   // J x1 (alpha = 1)
-      }
-      {
+      bool can = !lane_done && a == T(1) && corr != 0 && ((nl == 1 && ns == 0) || (nl == 0 && ns == 1));
+      if (REX_WAVE_ANY(can)) {
+        T Ut[S::NV], Un[S::NV], Ctt = T(0), Ctn = T(0), Cnn = T(0), wt = T(0), wn = T(0), jt1[NC], jn1[NC];
+        static_for<0, S::NV>([&](auto II) { Ut[II] = T(0); Un[II] = T(0); });
+        const bool lim_lane = !PAIR || par == 0u;   // the limit group is replicated: only one lane of a pair may add it
+        static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+          if constexpr (S::limited[j]) {
+            const bool b = ((t_lim >> j) & 1u) && lim_lane;
+            const T sg = ((m_lim >> j) & 1u) ? T(1) : T(-1);            // switched on / off
+            const T xr = C.lsig[j] * qacc[j + 2] - C.laref[j];          // the row at x1
+            Ut[j + 2] = b ? C.lsig[j] : T(0); Ctt += b ? sg * C.lD[j] : T(0); wt += b ? sg * C.lD[j] * xr : T(0); } });
+        for_slots<SLOTS>([&](auto KK) {
+          constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
+          const T mu = P.mu[gg]; const unsigned kk = k + par;
+          jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k];   // J x1 (alpha = 1)
+          const T x0 = jn1[k] + mu * jt1[k] - (C.an[k] + C.at[k]), x1 = jn1[k] - mu * jt1[k] - (C.an[k] - C.at[k]), x2 = jn1[k] - C.an[k];
+          const T d1_ = T(int((m_e1 >> kk) & 1u) - int((e1 >> kk) & 1u)), d2_ = T(int((m_e2 >> kk) & 1u) - int((e2 >> kk) & 1u)),
+                  d3_ = T(int((m_e3 >> kk) & 1u) - int((e3 >> kk) & 1u));   // +1 edge switched on, -1 off, 0 unchanged
+          const T any = ((tm >> kk) & 1u) ? T(1) : T(0);
+          const T Dk = C.D[k];
+          Ctt += Dk * mu * mu * (d1_ + d2_); Ctn += Dk * mu * (d1_ - d2_); Cnn += Dk * (d1_ + d2_ + T(2) * d3_);
+          wt += Dk * mu * (d1_ * x0 - d2_ * x1); wn += Dk * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
+          jt_accum_pre<T, S, b>(Jt[k], Jn[k], any, T(0), Ut);
+          jt_accum_pre<T, S, b>(Jt[k], Jn[k], T(0), any, Un);
+        });
+        T vt[S::NV], vn[S::NV];
+        static_for<0, S::NV>([&](auto II) { vt[II] = Ut[II]; vn[II] = Un[II]; });
+        ldl_solve<T, S>(H, vt); ldl_solve<T, S>(H, vn);
+        T Gtt = T(0), Gtn = T(0), Gnn = T(0);
+        static_for<0, S::NV>([&](auto II) { Gtt += Ut[II] * vt[II]; Gtn += Ut[II] * vn[II]; Gnn += Un[II] * vn[II]; });
+        const T a11 = T(1) + Ctt * Gtt + Ctn * Gtn, a12 = Ctt * Gtn + Ctn * Gnn, a21 = Ctn * Gtt + Cnn * Gtn, a22 = T(1) + Ctn * Gtn + Cnn * Gnn;
+        const T det = a11 * a22 - a12 * a21;
+        bool good = det > T(1e-3);
+        if constexpr (PAIR) good = good && (pair_xchg(good ? 1u : 0u) != 0u);
+        can = can && good;
+        const T idet = can ? rcp_t(det) : T(0);
+        const T zt = can ? (a22 * wt - a12 * wn) * idet : T(0), zn = can ? (a11 * wn - a21 * wt) * idet : T(0);
         T dx[S::NV];
-        // basis columns U = [j_t j_n] of the slot `sel` (one bit, or none), the change dC of its edge weights and w = the toggled
-        // edges' residual terms at x1
-        auto slot_group = [&](unsigned sel, T (&Ut)[S::NV], T (&Un)[S::NV], T& Ctt, T& Ctn, T& Cnn, T& wt, T& wn) {
-          static_for<0, S::NV>([&](auto II) { Ut[II] = T(0); Un[II] = T(0); });
-          Ctt = Ctn = Cnn = wt = wn = T(0);
-          for_slots<SLOTS>([&](auto KK) {
-            constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
-            const T mu = P.mu[gg]; const unsigned kk = k + par;
-            const T x0 = jn1[k] + mu * jt1[k] - (C.an[k] + C.at[k]), x1 = jn1[k] - mu * jt1[k] - (C.an[k] - C.at[k]), x2 = jn1[k] - C.an[k];
-            const T any = ((sel >> kk) & 1u) ? T(1) : T(0);
-            const T d1_ = any * T(int((g1 >> kk) & 1u) - int((e1 >> kk) & 1u)), d2_ = any * T(int((g2 >> kk) & 1u) - int((e2 >> kk) & 1u)),
-                    d3_ = any * T(int((g3 >> kk) & 1u) - int((e3 >> kk) & 1u));   // +1 edge switched on, -1 off, 0 unchanged
-            const T Dk = C.D[k];
-            Ctt += Dk * mu * mu * (d1_ + d2_); Ctn += Dk * mu * (d1_ - d2_); Cnn += Dk * (d1_ + d2_ + T(2) * d3_);
-            wt += Dk * mu * (d1_ * x0 - d2_ * x1); wn += Dk * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
-            jt_accum_pre<T, S, b>(Jt[k], Jn[k], any, T(0), Ut);
-            jt_accum_pre<T, S, b>(Jt[k], Jn[k], T(0), any, Un);
-          });
-        };
-        auto dotv = [&](const T (&x)[S::NV], const T (&y)[S::NV]) { T r = T(0); static_for<0, S::NV>([&](auto II) { r += x[II] * y[II]; }); return r; };
-        if (!BIG || !use_big) {
-          // ---- one group: a joint limit (its unit column rides in Ut) or one slot: 2 x 2
-          T Ut[S::NV], Un[S::NV], Ctt, Ctn, Cnn, wt, wn;
-          slot_group(sel1, Ut, Un, Ctt, Ctn, Cnn, wt, wn);
-          const bool lim_lane = !PAIR || par == 0u;   // the limit group is replicated: only one lane of a pair may add it
-          static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-            if constexpr (S::limited[j]) {
-              const bool b = ((t_lim >> j) & 1u) && lim_lane;
-              const T sg = ((g_lim >> j) & 1u) ? T(1) : T(-1);            // switched on / off
-              const T xr = C.lsig[j] * xb[j + 2] - C.laref[j];            // the row at x1
-              Ut[j + 2] += b ? C.lsig[j] : T(0); Ctt += b ? sg * C.lD[j] : T(0); wt += b ? sg * C.lD[j] * xr : T(0); } });
-          T vt[S::NV], vn[S::NV];
-          static_for<0, S::NV>([&](auto II) { vt[II] = Ut[II]; vn[II] = Un[II]; });
-          ldl_solve<T, S>(H, vt); ldl_solve<T, S>(H, vn);
-          const T Gtt = dotv(Ut, vt), Gtn = dotv(Ut, vn), Gnn = dotv(Un, vn);
-          const T a11 = T(1) + Ctt * Gtt + Ctn * Gtn, a12 = Ctt * Gtn + Ctn * Gnn, a21 = Ctn * Gtt + Cnn * Gtn, a22 = T(1) + Ctn * Gtn + Cnn * Gnn;
-          const T det = a11 * a22 - a12 * a21;
-          bool good = det > T(1e-3);
-          if constexpr (PAIR) good = good && (pair_xchg(good ? 1u : 0u) != 0u);
-          can = can && good;
-          const T idet = can ? rcp_t(det) : T(0);
-          const T zt = can ? (a22 * wt - a12 * wn) * idet : T(0), zn = can ? (a11 * wn - a21 * wt) * idet : T(0);
-          static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = zt * vt[i] + zn * vn[i];
-            if constexpr (PAIR) dx[i] += pair_xchg(dx[i]); });
-        } else {
-          // ---- several groups at once: the same Woodbury step with a 6 x 6 system.  Two column triples (l, t, n): a joint limit's
-          // unit column and the basis columns of one slot.  PAIR: triple A is the even lane's (the first toggled limit, the toggled
-          // slot of its end), triple B the odd lane's (the second toggled limit, its end's slot): each lane solves for its own three
-          // columns, the partner's V comes over the pair; every entry of G, dC and w is computed in ONE designated lane and handed
-          // over, so both lanes eliminate bit-identical systems.  One lane per env: both triples are this lane's.
-          const unsigned lim1 = t_lim & (0u - t_lim), lim2 = t_lim ^ lim1;
-          auto lim_group = [&](unsigned sel, T (&Ul)[S::NV], T& Cl, T& wl) {
-            static_for<0, S::NV>([&](auto II) { Ul[II] = T(0); });
-            Cl = wl = T(0);
-            static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-              if constexpr (S::limited[j]) {
-                const bool b = (sel >> j) & 1u;
-                const T sg = ((g_lim >> j) & 1u) ? T(1) : T(-1);            // switched on / off
-                const T xr = C.lsig[j] * xb[j + 2] - C.laref[j];            // the row at x1
-                Ul[j + 2] = b ? C.lsig[j] : T(0); Cl += b ? sg * C.lD[j] : T(0); wl += b ? sg * C.lD[j] * xr : T(0); } });
-          };
-          T Uo[3][S::NV], Vo[3][S::NV], Vp[3][S::NV], co[4], wo[3];   // own triple; co = (Cl, Ctt, Ctn, Cnn)
-          lim_group(PAIR ? (par ? lim2 : lim1) : lim1, Uo[0], co[0], wo[0]);
-          slot_group(sel1, Uo[1], Uo[2], co[1], co[2], co[3], wo[1], wo[2]);
-          static_for<0, 3>([&](auto QQ) { constexpr int q = QQ; static_for<0, S::NV>([&](auto II) { Vo[q][II] = Uo[q][II]; }); ldl_solve<T, S>(H, Vo[q]); });
-          T Gm[6][6], cA[4], cB[4], wv[6];
-          if constexpr (PAIR) {
-            static_for<0, 3>([&](auto QQ) { constexpr int q = QQ; static_for<0, S::NV>([&](auto II) { Vp[q][II] = pair_xchg(Vo[q][II]); }); });
-            const bool isB = par != 0u;
-            auto AB = [&](T mine, T& inA, T& inB) { const T other = pair_xchg(mine); inA = isB ? other : mine; inB = isB ? mine : other; };
-            static_for<0, 3>([&](auto II) { constexpr int i = II;
-              static_for<i, 3>([&](auto JJ) { constexpr int j = JJ; AB(dotv(Uo[i], Vo[j]), Gm[i][j], Gm[3 + i][3 + j]); });
-              static_for<0, 3>([&](auto JJ) { constexpr int j = JJ; T unused; AB(dotv(Uo[i], Vp[j]), Gm[i][3 + j], unused); }); });   // u_A . v_B: the even lane's value
-            static_for<0, 4>([&](auto QQ) { AB(co[QQ], cA[QQ], cB[QQ]); });
-            static_for<0, 3>([&](auto QQ) { AB(wo[QQ], wv[QQ], wv[3 + QQ]); });
-          } else {
-            T Up[3][S::NV];
-            lim_group(lim2, Up[0], cB[0], wv[3]);
-            slot_group(sel2, Up[1], Up[2], cB[1], cB[2], cB[3], wv[4], wv[5]);
-            static_for<0, 3>([&](auto QQ) { constexpr int q = QQ; static_for<0, S::NV>([&](auto II) { Vp[q][II] = Up[q][II]; }); ldl_solve<T, S>(H, Vp[q]); });
-            static_for<0, 3>([&](auto II) { constexpr int i = II;
-              static_for<i, 3>([&](auto JJ) { constexpr int j = JJ; Gm[i][j] = dotv(Uo[i], Vo[j]); Gm[3 + i][3 + j] = dotv(Up[i], Vp[j]); });
-              static_for<0, 3>([&](auto JJ) { constexpr int j = JJ; Gm[i][3 + j] = dotv(Uo[i], Vp[j]); }); });
-            static_for<0, 4>([&](auto QQ) { cA[QQ] = co[QQ]; });
-            static_for<0, 3>([&](auto QQ) { wv[QQ] = wo[QQ]; });
-          }
-          static_for<0, 6>([&](auto II) { constexpr int i = II; static_for<0, i>([&](auto JJ) { constexpr int j = JJ; Gm[i][j] = Gm[j][i]; }); });   // G is symmetric
-          // A = I + dC G, dC = diag(ClA, [cA], ClB, [cB]);  A z = w by elimination without pivoting (A is I plus a small
-          // perturbation in every accepted case; a pivot below 1e-3 rejects the correction)
-          T Am[6][6];
-          static_for<0, 6>([&](auto JJ) { constexpr int j = JJ;
-            Am[0][j] = cA[0] * Gm[0][j] + (j == 0 ? T(1) : T(0));
-            Am[1][j] = cA[1] * Gm[1][j] + cA[2] * Gm[2][j] + (j == 1 ? T(1) : T(0));
-            Am[2][j] = cA[2] * Gm[1][j] + cA[3] * Gm[2][j] + (j == 2 ? T(1) : T(0));
-            Am[3][j] = cB[0] * Gm[3][j] + (j == 3 ? T(1) : T(0));
-            Am[4][j] = cB[1] * Gm[4][j] + cB[2] * Gm[5][j] + (j == 4 ? T(1) : T(0));
-            Am[5][j] = cB[2] * Gm[4][j] + cB[3] * Gm[5][j] + (j == 5 ? T(1) : T(0)); });
-          bool good = true;
-          static_for<0, 6>([&](auto KK) { constexpr int k = KK;
-            good = good && Am[k][k] > T(1e-3);
-            const T ip = rcp_t(Am[k][k]);
-            static_for<k + 1, 6>([&](auto II) { constexpr int i = II;
-              const T f = Am[i][k] * ip;
-              static_for<k + 1, 6>([&](auto JJ) { constexpr int j = JJ; Am[i][j] -= f * Am[k][j]; });
-              wv[i] -= f * wv[k]; }); });
-          T z[6];
-          static_rfor<0, 6>([&](auto KK) { constexpr int k = KK;
-            T r = wv[k];
-            static_for<k + 1, 6>([&](auto JJ) { constexpr int j = JJ; r -= Am[k][j] * z[j]; });
-            z[k] = r * rcp_t(Am[k][k]); });
-          can = can && good;   // (PAIR: identical bits in both lanes, so they agree)
-          static_for<0, 6>([&](auto KK) { z[KK] = can ? z[KK] : T(0); });
-          if constexpr (PAIR) {
-            const T z0 = par ? z[3] : z[0], z1 = par ? z[4] : z[1], z2 = par ? z[5] : z[2];
-            static_for<0, S::NV>([&](auto II) { constexpr int i = II; const T o = z0 * Vo[0][i] + z1 * Vo[1][i] + z2 * Vo[2][i]; dx[i] = o + pair_xchg(o); });
-          } else {
-            static_for<0, S::NV>([&](auto II) { constexpr int i = II;
-              dx[i] = (z[0] * Vo[0][i] + z[1] * Vo[1][i] + z[2] * Vo[2][i]) + (z[3] * Vp[0][i] + z[4] * Vp[1][i] + z[5] * Vp[2][i]); });
-          }
-        }
-        static_for<0, S::NV>([&](auto II) { qacc[II] = can ? xb[II] - dx[II] : qacc[II]; });   // (a lane an earlier round finished keeps its point)
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = zt * vt[i] + zn * vn[i];
+          if constexpr (PAIR) dx[i] += pair_xchg(dx[i]);
+          qacc[i] -= dx[i]; });
         // the set at x2
         unsigned v_lim = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
         static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-          if constexpr (S::limited[j]) { const T x = C.lsig[j] * (xb[j + 2] - dx[j + 2]) - C.laref[j]; if (((C.lim_mask >> j) & 1u) && x < T(0)) v_lim |= 1u << j; } });
+          if constexpr (S::limited[j]) { const T x = C.lsig[j] * qacc[j + 2] - C.laref[j]; if (((C.lim_mask >> j) & 1u) && x < T(0)) v_lim |= 1u << j; } });
         for_slots<SLOTS>([&](auto KK) {
           constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
           const T mu = P.mu[gg]; const bool act = (C.con_mask >> (k + par)) & 1u;
@@ -1074,19 +958,16 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
 #if defined(REX_DIAG_CORR) && REX_DIAG_CORR >= 1
         const bool ok2 = true;
 #else
-        const bool ok2 = v_lim == g_lim && v1 == g1 && v2 == g2 && v3 == g3;
+        const bool ok2 = v_lim == m_lim && v1 == m_e1 && v2 == m_e2 && v3 == m_e3;
 #endif
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
         if (can) { gstats().toggles[3][3]++; if (ok2) gstats().toggles[3][2]++; }   // corrections tried / accepted
 #endif
         lane_done = lane_done || (can && ok2);
-        // x2 was computed for the target set: that is what the next gradient pass compares with
-        p_lim = can ? g_lim : p_lim; p_e1 = can ? g1 : p_e1; p_e2 = can ? g2 : p_e2; p_e3 = can ? g3 : p_e3;
-        pending = can && !ok2;
-        g_lim = v_lim; g1 = v1; g2 = v2; g3 = v3;   // (only read by the lanes still pending)
+        // x2 was computed for the set at x1: that is what the next gradient pass compares with
+        p_lim = can ? m_lim : p_lim; p_e1 = can ? m_e1 : p_e1; p_e2 = can ? m_e2 : p_e2; p_e3 = can ? m_e3 : p_e3;
         ma_dirty = true;
         REX_COUNT(nocon, 1);   // (diagnostic builds: slot "nocon" counts the correction trips of the wave)
-      }
       }
     }
     REX_PSTAMP(s_2, qacc[0] + amax);
@@ -1204,9 +1085,6 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
   } else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
 #if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
   if (mode == 3 && (threadIdx.x & 63) == 0) atomicAdd(&g_kstats[7], 1ull);   // wave-solves on the fast path
-#endif
-#if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (S::NSELF == 0) { if (mode == 1) REX_COUNT(selfpath, 1); }   // (slot "selfpath" of a chain without self pairs: general-path solves)
 #endif
 #if defined(REX_WAVETIME) && defined(__HIP_DEVICE_COMPILE__)
   if constexpr (S::NSELF == 0) { if (mode == 1) REX_COUNT(selfpath, 1); }   // (slot "selfpath" of a chain without self pairs: general-path solves)

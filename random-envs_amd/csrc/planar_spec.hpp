@@ -227,7 +227,7 @@ struct SolParams {
   T lim_K, lim_B, lim_dmin, lim_dmax, lim_width;
   T meaninertia;   // scale of the convergence test
   int ls_max;      // cap on extra line-search evaluations per Newton iteration (tuning knob)
-  int corr;        // Woodbury correction after a non-exact full step: 0 off, 1 one group (2 x 2), >= 2 up to four groups (6 x 6), `corr` - 1 rounds (tuning knob)
+  int corr;        // single-row Sherman-Morrison correction after a non-exact full step (tuning knob)
   int ls_free;     // leading Newton iterations of a solve that take the full step without a line search (tuning knob)
   int warm;        // start the solver from the previous evaluation's qacc (tuning knob)
   int fast;        // allow the feet-only straight-line solver instantiation (tuning knob / A-B tests; results agree to rounding)

@@ -778,6 +778,7 @@ struct rex_env {
   int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
   int pair = 1;                 // planar chains: two lanes per env (REX_PAIR=0: one lane per env)
   int hum_pair = 1;             // humanoid step: two lanes per env (humanoid_pair_step_kernel; REX_HUM_PAIR=0: one env per lane)
+  int fused_derive = 1;         // walker2d: the auto-reset under DR re-derives the lane's geometry inside the step kernel (REX_FUSED_DERIVE=0: reset + derive launches)
   // timing: event pool created by rex_enable_timing, used as a ring by rex_step (no allocation in the step path)
   int timing = 0;
   std::vector<hipEvent_t> ev0, ev1;
@@ -984,6 +985,10 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
   if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
   if (getenv("REX_HUM_PAIR")) h->hum_pair = atoi(getenv("REX_HUM_PAIR")) ? 1 : 0;
+  // walker2d: derive fused into the step kernel while the step is launch-latency bound (32 768 envs: + 10 % env-steps/s); from ~2^18 envs up
+  // the two small launches cost less than the derive does inside the step kernel's waves (2^20 envs: 238 M against 234 M env-steps/s)
+  h->fused_derive = batch < 262144 ? 1 : 0;
+  if (getenv("REX_FUSED_DERIVE")) h->fused_derive = atoi(getenv("REX_FUSED_DERIVE")) ? 1 : 0;
   if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
@@ -1147,9 +1152,9 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
   // planar envs reset finished lanes inside the step kernel (walker2d under DR re-derives the lane's geometry there as well)
   const bool walker_dr = h->kind == REX_WALKER2D && resample_on_reset && h->dr.type != REX_DR_NONE;
-  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || h->pair)))) ? 1 : 0;
+  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || (h->pair && h->fused_derive))))) ? 1 : 0;
   int rs = resample_on_reset ? RS_RESAMPLE : 0;
-  if (walker_dr && h->pair) rs |= RS_DERIVE | (h->variant ? RS_REFRESH : 0);
+  if (walker_dr && h->pair && h->fused_derive) rs |= RS_DERIVE | (h->variant ? RS_REFRESH : 0);
   // every `timing`-th launch is bracketed by two events of the pool rex_enable_timing created (ring): the two event packets
   // cost ~8 us of stream time per launch, 9 % of a hopper step, so a throughput run samples (bench.py: every 8th launch)
   const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;
