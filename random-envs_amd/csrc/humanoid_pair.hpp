@@ -657,6 +657,69 @@ REX_HD int solve_pgs(const P& p, const Model<T>& m, const PFactor<T>& F, const P
   return it;
 }
 
+// ---- pgs_sweeps_sq for the 16-row size over the pair (device, fp32): 256 matrix entries do not fit the VGPRs one lane has left during
+// the sweeps (they camp in AGPRs: a move per use), half of them do.  Lane 0 keeps res[0 .. NP/2), lane 1 res[NP/2 .. NP), so an update
+// of f_i pushes only HALF of row i per lane; the lane that owns res_i computes the new force, the partner gets it with one DPP move.
+// Every residual sees the same sequence of multiply-adds as in the replicated form: bit-identical results.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int NC, class P>
+__device__ __forceinline__ int pgs_sweeps_sq_pair(const P& p, const Model<float>& m, const float* col, float (&f)[DUAL_NMAX]) {
+  constexpr int NP = sq_stride(NC), BOFF = NP * NP, DOFF = BOFF + NP, NH = NP / 2;
+  static_assert(NH % 2 == 0 && NC <= DUAL_NMAX, "half rows are read as 8-byte words");
+  typedef pgs_v2f v2f;
+  const bool hi = p.side() != 0;
+  const float* const colh = col + (hi ? NH : 0);       // this lane's half of every row (8-byte aligned: NH is even)
+  const float scale = 1.0f / (m.meaninertia * float(NV));
+  v2f rp[NH / 2]; float fv[NC];
+  static_for<0, NH / 2>([&](auto QQ) { constexpr int q = QQ; rp[q] = *(const v2f*)(colh + BOFF + 2 * q); });
+  static_for<0, NC>([&](auto II) { fv[II] = 0.0f; });
+  float improvement = 0;
+  auto sweep = [&](auto CHECK) {
+    static_for<0, NC>([&](auto II) {
+      constexpr int i = II;
+      constexpr bool ownhi = i >= NH;                  // the lane that holds res_i (and A_ii in its half of row i)
+      constexpr int il = i - (ownhi ? NH : 0);
+      v2f a[NH / 2];
+      static_for<0, NH / 2>([&](auto QQ) { constexpr int q = QQ; a[q] = *(const v2f*)(colh + i * NP + 2 * q); });
+      const float di = col[DOFF + i];
+      const float res = (il & 1) ? rp[il / 2].y : rp[il / 2].x;
+      const float old = fv[i], nf_mine = __builtin_fmaxf(0.0f, old - res * di);
+      const float nf_other = p.xchg(nf_mine);
+      const bool owner = hi == ownhi;
+      const float nf = owner ? nf_mine : nf_other, df = nf - old;
+      fv[i] = nf;
+      if constexpr (decltype(CHECK)::value) {
+        const float aii = (il & 1) ? a[il / 2].y : a[il / 2].x;
+        const float term = df * (0.5f * df * aii + res);
+        improvement -= owner ? term : 0.0f;
+      }
+      const v2f dfp = {df, df};
+      static_for<0, NH / 2>([&](auto QQ) { constexpr int q = QQ; rp[q] = __builtin_elementwise_fma(a[q], dfp, rp[q]); });
+    });
+  };
+  int it = 0;
+  while (it < m.iterations) {
+    int nun = m.iterations - 1 - it; nun = nun < PGS_CHECK - 1 ? nun : PGS_CHECK - 1;
+#pragma unroll 1
+    for (int u = 0; u < nun; u++) { sweep(std::false_type{}); it++; }
+    improvement = 0;
+    sweep(std::true_type{}); it++;
+    improvement += p.xchg(improvement);                // (commutative: the same bits in both lanes)
+    if (improvement * scale < m.tolerance) break;
+  }
+  static_for<0, NC>([&](auto II) { f[II] = fv[II]; });
+  return it;
+}
+#endif
+template <int NC, class T, class P>
+REX_HD int pgs_sweeps_sq_split(const P& p, const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK) && !defined(REX_NO_SPLIT_SWEEPS)
+  if constexpr (sizeof(T) == 4) return pgs_sweeps_sq_pair<NC>(p, m, col, f);
+  else
+#endif
+  return pgs_sweeps_sq<NC>(m, col, f);
+}
+
 // ---- the dual PGS (A = J M^-1 J^T + R in the env's LDS column; humanoid_engine.hpp::solve_pgs_dual) with the row algebra
 // over the pair: every lane back-substitutes its own 16 columns, dot products are partial sums exchanged once ------------------
 template <class T, class P>
@@ -716,7 +779,7 @@ REX_HD int solve_pgs_dual(const P& p, const Model<T>& m, const PFactor<T>& F, PK
     case 2: it = pgs_sweeps_sq<10>(m, col, f); break;
     case 3: it = pgs_sweeps_sq<12>(m, col, f); break;
     case 4: it = pgs_sweeps_sq<14>(m, col, f); break;
-    case 5: it = pgs_sweeps_sq<16>(m, col, f); break;
+    case 5: it = pgs_sweeps_sq_split<16>(p, m, col, f); break;
     case 6: it = pgs_sweeps<18>(m, col, n, f); break;
     default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
   }
