@@ -720,6 +720,94 @@ REX_HD int pgs_sweeps_sq_split(const P& p, const Model<T>& m, const T* col, T (&
   return pgs_sweeps_sq<NC>(m, col, f);
 }
 
+// ---- 17 .. 21 rows over the pair: the PADDED lower triangle -- row r as r / 4 + 1 quads of four words at seg_off(r), b behind it, 1 / A_ii
+// formed from the diagonal -- with every row segment read ONCE per sweep: when row i is due, its segment A_i,0..i gives
+//   (1) the lower part of res_i:  sum_{j <= i} A_ij f_j   (f_j already this sweep's for j < i), and, once f_i is known,
+//   (2) the push of A_ij f_i into u_j, j <= i:            u_j collects sum_{k > j} A_kj f_k for row j's NEXT turn (A is symmetric),
+// so res_i = b_i + (1) + u_i - A_ii f_i (u_i also holds row i's own push of the previous sweep; f_i is still the old one in (1)).
+// The packed triangle's other half -- column i of the later rows, scattered words -- is never read.  Over the pair: lane h takes
+// words 2h, 2h + 1 of every quad (8-byte reads at a lane-constant offset, the same instruction in both lanes), keeps the forces and
+// the u of ITS columns as packed pairs, and the two partial sums of a row meet in one DPP add.  21 rows: 66 eight-byte reads + 132
+// v_pk_fma + ~13 instructions per row instead of the packed dot-product form's 222 scattered reads + 252 v_pk_fma + re-pairing moves
+// per lane (pgs_sweeps<21>: 837 instructions per sweep, the slowest waves of a launch).
+constexpr int seg_off(int r) { return 4 * ((r >> 2) + 1) * (2 * (r >> 2) + (r & 3)); }   // rows 4a .. 4a + 3 hold a + 1 quads each
+constexpr int SEG_B = seg_off(DUAL_NMAX);
+static_assert(seg_off(4) == 16 && SEG_B == 264 && SEG_B + DUAL_NMAX <= DUAL_WORDS, "padded triangle + b must fit the LDS column");
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int NC, class P>
+__device__ __forceinline__ int pgs_sweeps_seg_pair(const P& p, const Model<float>& m, const float* col, float (&f)[DUAL_NMAX]) {
+  typedef pgs_v2f v2f;
+  constexpr int NQ = (NC + 3) / 4;                       // quads of the longest row
+  const bool hi = p.side() != 0;
+  const float* const colh = col + (hi ? 2 : 0);          // this lane's two words of every quad
+  const float scale = 1.0f / (m.meaninertia * float(NV));
+  v2f fh[NQ], u[NQ], bh[NQ]; float fv[NC], dd[NC], aii[NC];
+  static_for<0, NQ>([&](auto QQ) { constexpr int q = QQ; fh[q] = v2f{0.0f, 0.0f}; u[q] = v2f{0.0f, 0.0f}; bh[q] = *(const v2f*)(colh + SEG_B + 4 * q); });
+  static_for<0, NC>([&](auto II) { constexpr int i = II; fv[i] = 0.0f; aii[i] = col[seg_off(i) + i]; dd[i] = aii[i] != 0.0f ? rcp_t(aii[i]) : 0.0f; });
+  float improvement = 0;
+  auto sweep = [&](auto CHECK) {
+    static_for<0, NC>([&](auto II) {
+      constexpr int i = II, Q = i / 4 + 1, qi = i / 4;
+      constexpr bool ownhi = ((i >> 1) & 1) != 0;        // the lane whose words hold column i
+      v2f a[Q];
+      static_for<0, Q>([&](auto QQ) { constexpr int q = QQ; a[q] = *(const v2f*)(colh + seg_off(i) + 4 * q); });
+      v2f acc = {0.0f, 0.0f};
+      static_for<0, Q>([&](auto QQ) { constexpr int q = QQ; acc = __builtin_elementwise_fma(a[q], fh[q], acc); });
+      const bool owner = hi == ownhi;
+      const float old = fv[i];
+      const float mine = ((i & 1) ? bh[qi].y : bh[qi].x) + ((i & 1) ? u[qi].y : u[qi].x) - aii[i] * old;   // b_i + u_i - A_ii f_i: the owner's
+      const float t = (acc.x + acc.y) + (owner ? mine : 0.0f);
+      const float res = t + p.xchg(t);                   // (commutative: the same bits in both lanes)
+      const float nf = __builtin_fmaxf(0.0f, old - res * dd[i]), df = nf - old;
+      fv[i] = nf;
+      if constexpr (decltype(CHECK)::value) improvement -= df * (0.5f * df * aii[i] + res);
+      if constexpr (i & 1) { fh[qi].y = owner ? nf : fh[qi].y; u[qi].y = owner ? 0.0f : u[qi].y; }
+      else { fh[qi].x = owner ? nf : fh[qi].x; u[qi].x = owner ? 0.0f : u[qi].x; }
+      const v2f nfp = {nf, nf};
+      static_for<0, Q>([&](auto QQ) { constexpr int q = QQ; u[q] = __builtin_elementwise_fma(a[q], nfp, u[q]); });
+    });
+  };
+  int it = 0;
+  while (it < m.iterations) {
+    int nun = m.iterations - 1 - it; nun = nun < PGS_CHECK - 1 ? nun : PGS_CHECK - 1;
+#pragma unroll 1
+    for (int k = 0; k < nun; k++) { sweep(std::false_type{}); it++; }
+    improvement = 0;
+    sweep(std::true_type{}); it++;
+    if (improvement * scale < m.tolerance) break;
+  }
+  static_for<0, NC>([&](auto II) { f[II] = fv[II]; });
+  static_for<NC, DUAL_NMAX>([&](auto II) { f[II] = 0.0f; });
+  return it;
+}
+#endif
+// the same Gauss-Seidel sweeps on the padded triangle, plain form (host builds; fp64 pins layout and algorithm)
+template <int NC, class T, class P>
+REX_HD int pgs_sweeps_seg(const P& p, const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(REX_NO_PK)
+  if constexpr (sizeof(T) == 4) return pgs_sweeps_seg_pair<NC>(p, m, col, f);
+  else
+#endif
+  {
+    auto A = [&](int i, int j) { return i >= j ? col[seg_off(i) + j] : col[seg_off(j) + i]; };
+    const T scale = T(1) / (m.meaninertia * T(NV));
+    int it = 0;
+    for (; it < m.iterations; it++) {
+      T improvement = 0;
+      for (int i = 0; i < NC; i++) {
+        T res = col[SEG_B + i];
+        for (int j = 0; j < NC; j++) res += A(i, j) * f[j];
+        const T a = A(i, i), di = a != T(0) ? rcp_t(a) : T(0);
+        const T old = f[i], nf = hmax(T(0), old - res * di), df = nf - old;
+        f[i] = nf;
+        improvement -= df * (T(0.5) * df * a + res);
+      }
+      if (improvement * scale < m.tolerance) { it++; break; }
+    }
+    return it;
+  }
+}
+
 // ---- the dual PGS (A = J M^-1 J^T + R in the env's LDS column; humanoid_engine.hpp::solve_pgs_dual) with the row algebra
 // over the pair: every lane back-substitutes its own 16 columns, dot products are partial sums exchanged once ------------------
 template <class T, class P>
@@ -732,9 +820,9 @@ REX_HD int solve_pgs_dual(const P& p, const Model<T>& m, const PFactor<T>& F, PK
 #if defined(__HIP_DEVICE_COMPILE__)
   lvl = __builtin_amdgcn_readfirstlane(lvl);
 #endif
-  const bool sq = lvl <= 5;
+  const bool sq = lvl <= 5;   // square rows up to 16 rows, the padded triangle (seg_off) above
   const int stride = lvl == 0 ? 4 : lvl == 1 ? 8 : lvl <= 3 ? 12 : 16;
-  const int boff = sq ? stride * stride : DUAL_B, doff = sq ? boff + stride : DUAL_DI;
+  const int boff = sq ? stride * stride : SEG_B, doff = boff + stride;
   static_for<0, DUAL_WORDS>([&](auto KK) { col[KK] = T(0); });   // (both lanes write the same zeros; padding must read as zero)
   for (int j0 = 0; j0 < n; j0 += 4) {
     T y[4][LD], Rr[4], ar[4];
@@ -743,7 +831,7 @@ REX_HD int solve_pgs_dual(const P& p, const Model<T>& m, const PFactor<T>& F, PK
     static_for<0, 4>([&](auto TT) { constexpr int t = TT; for (int k = 0; k < LD; k++) y[t][k] = s.J[jj[t]][k]; Rr[t] = s.R[jj[t]]; ar[t] = s.aref[jj[t]]; });
     static_for<0, 4>([&](auto TT) { constexpr int t = TT; const T b = pdot(p, y[t], K.qacc_smooth) - ar[t]; if (ok[t]) col[boff + j0 + t] = b; });
     solve_back<4>(p, F, y);
-    auto rowp = [&](int r) -> T* { return col + (sq ? r * stride : tri(r)); };
+    auto rowp = [&](int r) -> T* { return col + (sq ? r * stride : seg_off(r)); };
     auto put = [&](int r, int c, T v) { rowp(r)[c] = v; if (sq && c != r) col[c * stride + r] = v; };
     static_for<0, 4>([&](auto UU) {
       constexpr int u = UU;
@@ -751,7 +839,7 @@ REX_HD int solve_pgs_dual(const P& p, const Model<T>& m, const PFactor<T>& F, PK
       static_for<0, LD>([&](auto KK) { constexpr int k = KK; z[k] = y[u][k] * F.a[lidx(k, k)]; });
       if (ok[u]) for (int k = 0; k < LD; k++) s.J[j0 + u][k] = z[k];
       const T d = Rr[u] + pdot(p, z, y[u]);
-      if (ok[u]) { rowp(j0 + u)[j0 + u] = d; col[doff + j0 + u] = rcp_t(d); }
+      if (ok[u]) { rowp(j0 + u)[j0 + u] = d; if (sq) col[doff + j0 + u] = rcp_t(d); }
       static_for<u + 1, 4>([&](auto TT) { constexpr int t = TT; const T v = pdot(p, z, y[t]); if (ok[t]) put(j0 + t, j0 + u, v); });
     });
     T ra[LD], rb[LD];
@@ -780,8 +868,8 @@ REX_HD int solve_pgs_dual(const P& p, const Model<T>& m, const PFactor<T>& F, PK
     case 3: it = pgs_sweeps_sq<12>(m, col, f); break;
     case 4: it = pgs_sweeps_sq<14>(m, col, f); break;
     case 5: it = pgs_sweeps_sq_split<16>(p, m, col, f); break;
-    case 6: it = pgs_sweeps<18>(m, col, n, f); break;
-    default: it = pgs_sweeps<DUAL_NMAX>(m, col, n, f); break;
+    case 6: it = pgs_sweeps_seg<18>(p, m, col, f); break;
+    default: it = pgs_sweeps_seg<DUAL_NMAX>(p, m, col, f); break;
   }
   REX_HSTAMP(p2); REX_HACC(K, HT_SWEEPS, p1, p2); REX_HCNT(K, HC_SWEEPS, it);
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
