@@ -610,7 +610,7 @@ struct DevPair {
 __global__ void __launch_bounds__(64) humanoid_pair_step_kernel(DevState s, StepFlags fl, const float* __restrict__ action,
                                                                 float* __restrict__ obs, float* __restrict__ reward,
                                                                 unsigned char* __restrict__ done_out, unsigned char* __restrict__ trunc_out,
-                                                                float* __restrict__ term_obs) {
+                                                                float* __restrict__ term_obs, DRParams dr, int fused_reset, int resample) {
   namespace pr = hum::pr;
   const unsigned lane = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned i = lane >> 1;
@@ -686,20 +686,73 @@ __global__ void __launch_bounds__(64) humanoid_pair_step_kernel(DevState s, Step
       (s.qpos + (g + 1) * B)[i] = ql[ld + 1]; (s.qvel + g * B)[i] = vl[ld]; });
     static_for<3, pr::LB>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(left ? pr::gbL(lb) : pr::gbR(lb)) * B)[i] = xp[lb]; });
   }
-  if (left) return;
-  if (!fl.readonly) {
-    if (!finite) atomicAdd(s.counters + 0, 1ull);
-    if (kn.overflow) atomicAdd(s.counters + 3, 1ull);
-    s.t[i] = t;
-    static_for<0, 10>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = ql[k]; });
-    static_for<0, 9>([&](auto KK) { constexpr int k = KK; (s.qvel + (size_t)k * B)[i] = vl[k]; });
-    static_for<0, 3>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(lb + 1) * B)[i] = xp[lb]; });
-    s.aux[i] = 0.0f;                                                // world body
-    s.done[i] = d ? 2 : 0;
+  if (!left) {
+    if (!fl.readonly) {
+      if (!finite) atomicAdd(s.counters + 0, 1ull);
+      if (kn.overflow) atomicAdd(s.counters + 3, 1ull);
+      s.t[i] = t;
+      static_for<0, 10>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = ql[k]; });
+      static_for<0, 9>([&](auto KK) { constexpr int k = KK; (s.qvel + (size_t)k * B)[i] = vl[k]; });
+      static_for<0, 3>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(lb + 1) * B)[i] = xp[lb]; });
+      s.aux[i] = 0.0f;                                                // world body
+      s.done[i] = d ? 2 : 0;
+    }
+    if (fl.info) for (int k = 0; k < 4; k++) (fl.info + k * B)[i] = terms[k];   // reward_linvel, _quadctrl, _alive, _impact (random_humanoid.py:182-187)
+    reward[i] = r; done_out[i] = d ? 1 : 0;
+    if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
   }
-  if (fl.info) for (int k = 0; k < 4; k++) (fl.info + k * B)[i] = terms[k];   // reward_linvel, _quadctrl, _alive, _impact (random_humanoid.py:182-187)
-  reward[i] = r; done_out[i] = d ? 1 : 0;
-  if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+  // Auto-reset fused into the step launch (the masked reset launch behind every step was 80 us of a 1.77 ms step): a finished env
+  // restarts here, both lanes of its pair.  reset_model (random_humanoid.py:219-234) exactly as humanoid_reset_kernel does it -- the same
+  // Philox streams and draw order (q 0..23, then v 0..22), set_state -> sim.forward() with the masses in force, THEN
+  // set_random_task -- with the forward's kinematics / com / velocities over the pair's local trees.
+  if (fused_reset && d) {
+    const unsigned ep = s.episode[i] + 1;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE, &st);
+    static_for<0, hum::NQ>([&](auto KK) { constexpr int k = KK;
+      const float val = c_hum.qpos0[k] + 0.01f * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
+      if constexpr (k < 10) ql[k] = val;                              // free joint + the three abdomen hinges: replicated
+      else static_for<9, pr::LD>([&](auto DD) { constexpr int ld = DD;
+        if constexpr (pr::gdR(ld) + 1 == k) ql[ld + 1] = left ? ql[ld + 1] : val;
+        if constexpr (pr::gdL(ld) + 1 == k) ql[ld + 1] = left ? val : ql[ld + 1]; }); });
+    static_for<0, hum::NV>([&](auto KK) { constexpr int k = KK;
+      const float val = 0.01f * (2.0f * (1.0f - rocrand_uniform(&st)) - 1.0f);
+      if constexpr (k < 9) vl[k] = val;
+      else static_for<9, pr::LD>([&](auto DD) { constexpr int ld = DD;
+        if constexpr (pr::gdR(ld) == k) vl[ld] = left ? vl[ld] : val;
+        if constexpr (pr::gdL(ld) == k) vl[ld] = left ? val : vl[ld]; }); });
+    {
+      pr::PSmooth<float> S;
+      pr::kinematics(p, c_hum, ql, S);
+      pr::com_pos(p, c_hum, L, S);
+      float qb[pr::LD];
+      pr::com_vel_rne(p, c_hum, vl, S, qb);
+      static_for<0, pr::LB>([&](auto BB) { constexpr int b = BB; for (int k = 0; k < 10; k++) park.cinert[b][k] = S.cinert[b][k]; for (int k = 0; k < 6; k++) park.cvel[b][k] = S.cvel[b][k]; xp[b] = S.xipos[b][0]; });
+      static_for<0, pr::LD>([&](auto II) { park.act[II] = 0.0f; });     // sim.reset() zeroes data.ctrl
+    }
+    if (fl.noisy) {
+      rocrand_state_philox4x32_10 st2;
+      rocrand_init(s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + STEP_BASE, &st2);
+      for (int k = 0; k < 45; k++) nz[k] = fl.noise_std * rocrand_normal(&st2);
+    }
+    pr::emit_obs(p, ql, vl, park, [&](auto RR, auto RL, float val) {
+      constexpr int rr = RR, rl = RL;
+      if constexpr (rr < 45 && rl < 45) { if (fl.noisy) val += left ? nz[rl] : nz[rr]; }
+      (obs + (left ? (size_t)rl : (size_t)rr) * B)[i] = val;
+    });
+    static_for<9, pr::LD>([&](auto DD) { constexpr int ld = DD; const size_t g = left ? pr::gdL(ld) : pr::gdR(ld);
+      (s.qpos + (g + 1) * B)[i] = ql[ld + 1]; (s.qvel + g * B)[i] = vl[ld]; });
+    static_for<3, pr::LB>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(left ? pr::gbL(lb) : pr::gbR(lb)) * B)[i] = xp[lb]; });
+    if (!left) {
+      s.episode[i] = ep;
+      static_for<0, 10>([&](auto KK) { constexpr int k = KK; (s.qpos + (size_t)k * B)[i] = ql[k]; });
+      static_for<0, 9>([&](auto KK) { constexpr int k = KK; (s.qvel + (size_t)k * B)[i] = vl[k]; });
+      static_for<0, 3>([&](auto BB) { constexpr int lb = BB; (s.aux + (size_t)(lb + 1) * B)[i] = xp[lb]; });
+      s.t[i] = 0; s.done[i] = 0;
+      if (resample && dr.type != REX_DR_NONE)
+        sample_task(dr, s.seed, (unsigned long long)(s.env_offset + i), (unsigned long long)ep * EP_STRIDE + 256, s.xi, B, i, s.counters);
+    }
+  }
 }
 
 // reset_model (random_humanoid.py:219-234): init noise U(-.01,.01) on all of qpos (incl. the quaternion) and qvel,
@@ -778,6 +831,7 @@ struct rex_env {
   int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
   int pair = 1;                 // planar chains: two lanes per env (REX_PAIR=0: one lane per env)
   int hum_pair = 1;             // humanoid step: two lanes per env (humanoid_pair_step_kernel; REX_HUM_PAIR=0: one env per lane)
+  int hum_fused_reset = 1;      // humanoid pair step: finished envs restart inside the step launch (REX_HUM_FUSED_RESET=0: the masked reset launch)
   int fused_derive = 1;         // walker2d: the auto-reset under DR re-derives the lane's geometry inside the step kernel (REX_FUSED_DERIVE=0: reset + derive launches)
   // timing: event pool created by rex_enable_timing, used as a ring by rex_step (no allocation in the step path)
   int timing = 0;
@@ -985,6 +1039,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
   if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
   if (getenv("REX_HUM_PAIR")) h->hum_pair = atoi(getenv("REX_HUM_PAIR")) ? 1 : 0;
+  if (getenv("REX_HUM_FUSED_RESET")) h->hum_fused_reset = atoi(getenv("REX_HUM_FUSED_RESET")) ? 1 : 0;
   // walker2d: derive fused into the step kernel while the step is launch-latency bound (32 768 envs: + 10 % env-steps/s); from ~2^18 envs up
   // the two small launches cost less than the derive does inside the step kernel's waves (2^20 envs: 238 M against 234 M env-steps/s)
   h->fused_derive = batch < 262144 ? 1 : 0;
@@ -1130,11 +1185,11 @@ static void launch_planar_step(rex_env* h, const DevState& dev, const StepFlags&
 
 #if REX_EN_HUMANOID
 static void launch_humanoid_step(rex_env* h, const DevState& dev, const StepFlags& flags, const float* action, float* obs_out, float* reward_out,
-                                 uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out, hipStream_t st) {
+                                 uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out, hipStream_t st, int fused = 0, int resample = 0) {
   if (h->hum_pair) {   // 2 B lanes in 64-lane blocks: 32 envs per wave, one LDS column per env
     const unsigned blocks = (unsigned)((2 * h->B + 63) / 64);
     hipLaunchKernelGGL(humanoid_pair_step_kernel, dim3(blocks), dim3(64), sizeof(float) * hum::pr::PAIR_WORDS * 32, st, dev, flags, action, obs_out,
-                       reward_out, done_out, truncated_out, terminal_obs_out);
+                       reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
   } else {
     hipLaunchKernelGGL(humanoid_step_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, flags, action, obs_out, reward_out,
                        done_out, truncated_out, terminal_obs_out);
@@ -1152,7 +1207,8 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
   // planar envs reset finished lanes inside the step kernel (walker2d under DR re-derives the lane's geometry there as well)
   const bool walker_dr = h->kind == REX_WALKER2D && resample_on_reset && h->dr.type != REX_DR_NONE;
-  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || (h->pair && h->fused_derive))))) ? 1 : 0;
+  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || (h->pair && h->fused_derive))) ||
+                                      (h->kind == REX_HUMANOID && h->hum_pair && h->hum_fused_reset))) ? 1 : 0;
   int rs = resample_on_reset ? RS_RESAMPLE : 0;
   if (walker_dr && h->pair && h->fused_derive) rs |= RS_DERIVE | (h->variant ? RS_REFRESH : 0);
   // every `timing`-th launch is bracketed by two events of the pool rex_enable_timing created (ring): the two event packets
@@ -1179,7 +1235,7 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
 #endif
 #if REX_EN_HUMANOID
     case REX_HUMANOID:
-      launch_humanoid_step(h, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, st); break;
+      launch_humanoid_step(h, h->dev, h->flags, (const float*)action, obs_out, reward_out, done_out, truncated_out, terminal_obs_out, st, fused, resample_on_reset); break;
 #endif
   }
   if (timed) { HIP_TRY(hipEventRecord(h->ev1[ev_slot], st)); h->ev_n++; }

@@ -268,3 +268,46 @@ def test_crouched_states_every_sweep_layout(torch_mod):
     assert np.median(ev[ok]) < 1e-5, np.median(ev[ok])
     assert_lanes_explained(ev[ok], (sens["qvel"] / vs)[ok], 1e-4, 5e-1, K=256.0, label="humanoid crouched states |dqvel|rel")
     env.close()
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_autoreset_observation_vs_oracle(torch_mod, fused):
+    """a9 / SURVEY Q10 on the AUTO-reset path: a finished env restarts inside the step launch (humanoid_pair_step_kernel; the masked
+    humanoid_reset_kernel launch with REX_HUM_FUSED_RESET=0).  The observation a finished lane returns is reset_model()'s: the
+    new state's sim.forward() with the masses the episode that just ended had, against oracle/mjo_humanoid.c; its task is redrawn
+    afterwards, the other lanes' tasks stay; data.xipos of the new state is what the next mass_center() reads."""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_humanoid_reset_obs
+    from parity_util import create_knobs
+    torch = torch_mod
+    B = 4096
+    with create_knobs(REX_HUM_FUSED_RESET=fused):
+        env = rex.make("RandomHumanoid-v0", batch=B, seed=13)
+    lo, hi = env.get_task_search_bounds()
+    env.set_dr_distribution("uniform", np.stack([lo, hi], 1).ravel().tolist()); env.set_dr_training(True)
+    env.reset()
+    g = torch.Generator().manual_seed(1); checked = 0
+    for t in range(60):
+        xi_before = env.get_task().cpu().numpy().astype(np.float64)
+        obs, r, d, info = env.step(torch.rand(B, 17, generator=g) * 0.8 - 0.4)
+        idx = np.where(d.cpu().numpy())[0]
+        if len(idx) < 16:
+            continue
+        q, v = env.get_state()
+        q = q.cpu().numpy().astype(np.float64)[idx]; v = v.cpu().numpy().astype(np.float64)[idx]
+        assert np.abs(q - np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17)).max() <= 0.01 + 1e-6 and np.abs(v).max() <= 0.01 + 1e-7
+        ref, xip = oracle_humanoid_reset_obs(q, v, xi_before[idx])
+        o = obs.cpu().numpy().astype(np.float64)[idx]
+        e = np.abs(o - ref).max(1) / (1 + np.abs(ref).max(1))
+        assert e.max() < 2e-5, (fused, e.max())
+        xi_after = env.get_task().cpu().numpy().astype(np.float64)
+        keep = np.ones(B, bool); keep[idx] = False
+        assert np.array_equal(xi_after[keep], xi_before[keep]) and np.abs(xi_after[idx] - xi_before[idx]).max(1).min() > 1e-3
+        aux = env.get_full_state()["aux"].t().cpu().numpy()[idx]
+        assert np.abs(aux - xip).max() < 1e-5
+        checked += len(idx)
+        if checked >= 256:
+            break
+    assert checked >= 64, checked
+    c = env.counters(); assert c["nonfinite"] == 0 and c["overflow"] == 0
+    env.close()
