@@ -311,3 +311,29 @@ def test_autoreset_observation_vs_oracle(torch_mod, fused):
     assert checked >= 64, checked
     c = env.counters(); assert c["nonfinite"] == 0 and c["overflow"] == 0
     env.close()
+
+
+def test_one_lane_step_kernel_matches_the_oracle(torch_mod):
+    """REX_HUM_PAIR=0: the one-env-per-lane step kernel (humanoid_step_kernel over humanoid_engine.hpp), kept behind the knob as
+    the A/B partner of the pair kernel: same oracle, same per-lane gates; and the two kernels agree with each other."""
+    import random_envs_amd as rex
+    from oracle_bindings import oracle_humanoid_step, oracle_sensitivity
+    from parity_util import assert_lanes_explained, create_knobs
+    torch = torch_mod
+    n = 512
+    q, v, a, xi = _states(n, 17)
+    outs = []
+    for pair in (0, 1):
+        with create_knobs(REX_HUM_PAIR=pair):
+            env = rex.make("RandomHumanoid-v0", batch=n, autoreset=False)
+        env.set_task(xi.astype(np.float32)); env.set_state(q, v)
+        obs, r, d, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+        outs.append((obs.cpu().numpy().astype(np.float64), r.cpu().numpy().astype(np.float64), env.counters()))
+        env.close()
+    ref, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_humanoid_step(q_, v_, a_, x_), [q, v, a, xi], ["obs", "reward"], trials=2)
+    os_ = 1 + np.abs(ref["obs"]).max(1)
+    for pair, (o, r, c) in zip((0, 1), outs):
+        assert c["nonfinite"] == 0 and c["overflow"] == 0
+        assert_lanes_explained(np.abs(o - ref["obs"]).max(1) / os_, sens["obs"] / os_, TOL_OBS, CAP_OBS, label="humanoid REX_HUM_PAIR=%d |dobs|rel" % pair)
+        assert_lanes_explained(np.abs(r - ref["reward"]), sens["reward"], TOL_REW, CAP_REW, label="humanoid REX_HUM_PAIR=%d |dreward|" % pair)
+    assert_lanes_explained(np.abs(outs[0][0] - outs[1][0]).max(1) / os_, sens["obs"] / os_, TOL_OBS, CAP_OBS, label="one-lane vs pair kernel |dobs|rel")
