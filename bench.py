@@ -35,10 +35,23 @@ ENV_ID = "RandomHopper-v0"
 BATCH_PER_GPU = 32768
 # algorithmic bytes per env-step = read (qpos,qvel,action,xi) + write (qpos,qvel,obs,reward,done)
 BYTES_PER_KIND = {"hopper": 173, "walker2d": 293, "halfcheetah": 273, "cartpole": 73, "humanoid": 2073}
-# the names rocprofv3 / profiles/hbm_traffic.json show for the launched instantiation (PAIR = two lanes per env)
-KERNEL_OF_KIND = {"hopper": "planar_step_kernel<rex::HopperSpec, true>", "walker2d": "planar_step_kernel<rex::Walker2dSpec, true>",
-                  "halfcheetah": "planar_step_kernel<rex::HalfCheetahSpec, true>", "cartpole": "cartpole_step_kernel",
-                  "humanoid": "humanoid_pair_step_kernel"}
+# the names rocprofv3 / profiles/hbm_traffic.json show for the launched instantiation: <spec, PAIR = two lanes per env, ROLLED>
+PLANAR_SPEC = {"hopper": "HopperSpec", "walker2d": "Walker2dSpec", "halfcheetah": "HalfCheetahSpec"}
+
+
+def kernel_of(kind, batch):
+    """rex_create's launch shape by batch (rex_hip.hip, on MI355X's 1 024 SIMDs): planar chains run two lanes per env up to 32 768 envs and one
+    lane per env past that; the hopper past 65 536 envs launches the 256-register / two-waves-per-SIMD kernel with the rolled general solver
+    (REX_PAIR / REX_ROLLED / REX_FAST override)."""
+    if kind == "cartpole":
+        return "cartpole_step_kernel"
+    if kind == "humanoid":
+        return "humanoid_pair_step_kernel" if int(os.environ.get("REX_HUM_PAIR", "1")) else "humanoid_step_kernel"
+    pair = (int(os.environ["REX_PAIR"]) != 0 if "REX_PAIR" in os.environ else batch <= 32768) and int(os.environ.get("REX_FAST", "1")) != 0
+    rolled = kind == "hopper" and not pair and (int(os.environ["REX_ROLLED"]) != 0 if "REX_ROLLED" in os.environ else batch > 65536)
+    return "planar_step_kernel<rex::%s, %s, %s>" % (PLANAR_SPEC[kind], "true" if pair else "false", "true" if rolled else "false")
+
+
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -332,7 +345,7 @@ def main():
                                       "asynchronously every %d steps" % (world, args.scaling, args.counter_every)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": KERNEL_OF_KIND[kind], "kernel_avg_ms": kavg_ms, "kernel_launches_timed": len(kernel_ms_ext),
+                         "kernel": kernel_of(kind, B), "kernel_avg_ms": kavg_ms, "kernel_launches_timed": len(kernel_ms_ext),
                          "kernel_launches_timed_in_region": n_k, "kernel_avg_ms_in_region": kavg_region if n_k else None,
                          "algorithmic_bytes_per_launch": bytes_step * B, "bytes_per_env_step": bytes_step,
                          # the same fraction on the WALL clock of the timed region (what `value` is computed from)

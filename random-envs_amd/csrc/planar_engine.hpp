@@ -978,6 +978,144 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
   return st;
 }
 
+// The general instantiation, ROLLED (template flag of forward() / substep()): the same primal Newton solve over an explicit list of constraint rows -- joint
+// limits, the pyramid edges n + mu t, n - mu t, n (weight 2) of every floor slot inside the margin, capsule-capsule self rows -- kept in
+// runtime-indexed local arrays (scratch on the device) and walked by runtime loops.  Far slower per solve than the unrolled general
+// instantiation, and far smaller in registers: for a chain whose batches practically never leave the feet-only path (the hopper: 100 % of
+// the wave-solves under a random policy) the kernel's register allocation is then the feet-only path's own -- 256 VGPRs, no AGPR --, so TWO
+// waves share a SIMD and fill each other's issue slots.  That pays as soon as some SIMD has two waves to run: above 32 768 envs per GPU
+// (34 816 envs: 261 -> 296 M env-steps/s, 2^20: 519 -> 904 M); up to 32 768 envs every wave has a SIMD to itself and the feet-only path is
+// 5-20 % slower on 256 registers than on 461, so those batches keep the unrolled general instantiation (rex_hip.hip picks per handle).
+template <class T, class S>
+struct RowList {
+  static constexpr int MAXR = (S::NB - 1) + 3 * 2 * S::NG + (S::NSELF > 0 ? 2 * S::NSELF : 0);
+  T J[MAXR][S::NV], D[MAXR], aref[MAXR];
+  int n;
+};
+template <class T, class S>
+REX_HD void build_rows(const Kin<T, S>& K, const Constraints<T, S>& C, const SelfRows<T, S>& R, const LaneParams<T, S>& P, bool self, RowList<T, S>& L) {
+  int n = 0;
+  auto push = [&](const T (&row)[S::NV], T D, T aref) { for (int k = 0; k < S::NV; k++) L.J[n][k] = row[k]; L.D[n] = D; L.aref[n] = aref; n++; };
+  static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+    if constexpr (S::limited[j]) { if ((C.lim_mask >> j) & 1u) { T row[S::NV]; static_for<0, S::NV>([&](auto II) { row[II] = T(0); }); row[j + 2] = C.lsig[j]; push(row, C.lD[j], C.laref[j]); } } });
+  static_for<0, 2 * S::NG>([&](auto KK) { constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
+    if (REX_WAVE_ANY((C.con_mask >> k) & 1u)) {
+      if ((C.con_mask >> k) & 1u) {
+        T ut[S::NV], un[S::NV];
+        static_for<0, S::NV>([&](auto II) { ut[II] = T(0); un[II] = T(0); });
+        jt_accum<T, S, b>(K, C.px[k], C.pz[k], T(1), T(0), ut); jt_accum<T, S, b>(K, C.px[k], C.pz[k], T(0), T(1), un);
+        const T mu = P.mu[gg];
+        T r1[S::NV], r2[S::NV];
+        static_for<0, S::NV>([&](auto II) { r1[II] = un[II] + mu * ut[II]; r2[II] = un[II] - mu * ut[II]; });
+        push(r1, C.D[k], C.an[k] + C.at[k]); push(r2, C.D[k], C.an[k] - C.at[k]); push(un, T(2) * C.D[k], C.an[k]);
+      }
+    } });
+  if constexpr (S::NSELF > 0) {
+    if (self) static_for<0, 2 * S::NSELF>([&](auto PP) { constexpr int q = PP; constexpr int ba = S::geom_body[S::self_a[q / 2]], bb = S::geom_body[S::self_b[q / 2]];
+      if ((R.mask >> q) & 1u) {
+        T row[S::NV]; static_for<0, S::NV>([&](auto II) { row[II] = T(0); });
+        jt_accum<T, S, bb>(K, R.px[q], R.pz[q], R.nx[q], R.nz[q], row); jt_accum<T, S, ba>(K, R.px[q], R.pz[q], -R.nx[q], -R.nz[q], row);
+        push(row, R.D[q], R.aref[q]);
+      } });
+  }
+  L.n = n;
+}
+template <class T, class S, int MAXIT = 24>
+REX_HD SolveStats solve_newton_rolled(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV], const RowList<T, S>& L,
+                                      T (&qacc)[S::NV], bool warm, bool have_a0, int ls_max, int ls_free) {
+  const int n = L.n;
+  const bool has_rows = n > 0;
+  static_for<0, S::NV>([&](auto II) { T prev = qacc[II], cold = qacc_smooth[II]; opaque(prev); opaque(cold);
+                                      qacc[II] = have_a0 ? ((warm && has_rows) ? prev : cold) : prev; });
+  SolveStats st{0, false, 0};
+  const T tol2 = sizeof(T) == 4 ? T(1e-9) : T(1e-24);
+  const T stag = sizeof(T) == 4 ? T(1e-6) : T(1e-15);
+  unsigned long long p_on = ~0ull;
+  bool lane_done = !has_rows && have_a0;
+  static_assert(RowList<T, S>::MAXR <= 64, "active-row mask");
+  for (int it = 0; it < MAXIT; ++it) {
+    if (!REX_WAVE_ANY(!lane_done)) break;
+    T Ma[S::NV], g[S::NV];
+    sym_matvec<T, S>(M, qacc, Ma);
+    T fref = T(0);
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] = Ma[i] - qfrc_smooth[i]; fref += Ma[i] * Ma[i] + qfrc_smooth[i] * qfrc_smooth[i]; });
+    unsigned long long on = 0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < n; r++) {
+      T jar = -L.aref[r];
+      static_for<0, S::NV>([&](auto II) { jar += L.J[r][II] * qacc[II]; });
+      if (jar < T(0)) { on |= 1ull << r; const T w = L.D[r] * jar; static_for<0, S::NV>([&](auto II) { g[II] += L.J[r][II] * w; }); }
+    }
+    T gn = T(0);
+    static_for<0, S::NV>([&](auto II) { gn += g[II] * g[II]; });
+    const bool same_set = on == p_on;
+    p_on = on;
+    lane_done = lane_done || same_set || !(gn > tol2 * fref);
+    if (!REX_WAVE_ANY(!lane_done)) break;
+    T H[S::NV][S::NV];
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] = M[i][j]; }); });
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < n; r++) {
+      if ((on >> r) & 1ull) {
+        T row[S::NV]; static_for<0, S::NV>([&](auto II) { row[II] = L.J[r][II]; });
+        const T d = L.D[r];
+        static_for<0, S::NV>([&](auto AA) { constexpr int a = AA;
+          static_for<0, a + 1>([&](auto BB) { constexpr int b = BB; if constexpr (dof_coupled<S>(a, b)) H[a][b] += d * row[a] * row[b]; }); });
+      }
+    }
+    ldl_factor<T, S>(H);
+    T sr[S::NV];
+    static_for<0, S::NV>([&](auto II) { sr[II] = -g[II]; });
+    ldl_solve<T, S>(H, sr);
+    T Ms[S::NV];
+    sym_matvec<T, S>(M, sr, Ms);
+    T q1 = T(0), q2 = T(0), d0 = T(0);
+    static_for<0, S::NV>([&](auto II) { q1 += sr[II] * (Ma[II] - qfrc_smooth[II]); q2 += sr[II] * Ms[II]; d0 += sr[II] * g[II]; });
+    unsigned long long m_on = 0ull;
+    auto deriv = [&](T a, T& d1, T& d2) {
+      m_on = 0ull; d1 = q1 + a * q2; d2 = q2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+      for (int r = 0; r < n; r++) {
+        T x = -L.aref[r], vv = T(0);
+        static_for<0, S::NV>([&](auto II) { x += L.J[r][II] * qacc[II]; vv += L.J[r][II] * sr[II]; });
+        x += a * vv;
+        if (x < T(0)) { m_on |= 1ull << r; d1 += L.D[r] * x * vv; d2 += L.D[r] * vv * vv; }
+      }
+    };
+    const T d1ref = abs_t(d0) * T(sizeof(T) == 4 ? 1e-5 : 1e-13) + T(1e-30);
+    T a = T(1), lo = T(0), hi = T(-1), d1, d2;
+    deriv(a, d1, d2);
+    bool ls_done = lane_done || abs_t(d1) <= d1ref;
+    const int ls_cap = it < ls_free ? 0 : ls_max;
+    for (int ls = 0; ls < ls_cap; ++ls) {
+      if (!REX_WAVE_ANY(!ls_done)) break;
+      if (d1 < T(0)) lo = a; else hi = a;
+      T an_ = a - d1 * rcp_t(d2);
+      if (hi >= T(0) && (an_ <= lo || an_ >= hi)) an_ = T(0.5) * (lo + hi);
+      an_ = max_t(an_, lo);
+      T prev = a;
+      a = ls_done ? a : an_;
+      deriv(a, d1, d2);
+      ls_done = ls_done || abs_t(d1) <= d1ref || a == prev;
+    }
+    const bool exact_step = a == T(1) && m_on == on;
+    a = lane_done ? T(0) : a;
+    T amax = T(0), smax = T(0);
+    static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; amax = max_t(amax, abs_t(qacc[II])); smax = max_t(smax, abs_t(a * sr[II])); });
+    lane_done = lane_done || exact_step || smax <= stag * (T(1) + amax);
+    st.iters = it + 1;
+    if (it == MAXIT - 1) st.capped = REX_WAVE_ANY(!lane_done);
+  }
+  return st;
+}
+
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
 // diagnostic build only: per-phase cycle stamps (s_memtime), summed per wave into g_ktime[]
 extern __device__ unsigned long long g_ktime[24 + 72];
@@ -989,7 +1127,7 @@ extern __device__ unsigned long long g_ktime[24 + 72];
 #endif
 
 // one forward-dynamics evaluation: qacc(q, v, ctrl)  ([3P] mj_forward)
-template <class T, class S, bool PAIR = false>
+template <class T, class S, bool PAIR = false, bool ROLLED = false>
 REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
                           const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV],
                           bool warm = false) {
@@ -1075,13 +1213,23 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
       slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
       st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr);
     }
+  } else if (ROLLED && (mode == 1 || mode == 2)) {   // (one call site for both: the row list carries the self rows when there are any)
+    if constexpr (ROLLED) {
+      if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
+      slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
+      RowList<T, S> RL;
+      build_rows<T, S>(K, C, R, P, mode == 2, RL);
+      st = solve_newton_rolled<T, S>(M, f, a0, RL, qacc, warm, have_a0, sp.ls_max, sp.ls_free);
+    }
   } else if (mode == 2) {
     if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);   // the general instantiations run replicated in both lanes of a pair: every slot
-    if constexpr (S::NSELF > 0) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr); }
+    if constexpr (S::NSELF > 0 && !ROLLED) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr); }
   } else if (mode == 1) {
-    if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
-    slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
-    st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr);
+    if constexpr (!ROLLED) {
+      if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
+      slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
+      st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr);
+    }
   } else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
 #if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
   if (mode == 3 && (threadIdx.x & 63) == 0) atomicAdd(&g_kstats[7], 1ull);   // wave-solves on the fast path
@@ -1106,7 +1254,7 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
 
 // one mj_step: RK4 ([3P] mj_RungeKutta, N=4) or semi-implicit Euler with implicit joint damping
 // ([3P] mj_Euler).  Returns the OR of "solver hit its cap".
-template <class T, class S, bool PAIR = false>
+template <class T, class S, bool PAIR = false, bool ROLLED = false>
 REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
                     const LaneParams<T, S>& P, const SolParams<T>& sp, T (&acc)[S::NV], bool warm) {
   // acc: in = qacc of the previous evaluation (solver warm start when `warm`), out = qacc of the last one
@@ -1120,7 +1268,7 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
     static_for<0, S::NV>([&](auto II) { q0[II] = q[II]; v0[II] = v[II]; dq[II] = T(0); dv[II] = T(0); });
 #pragma unroll 1
     for (int stage = 0; stage < 4; ++stage) {
-      capped |= forward<T, S, PAIR>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0)).capped;
+      capped |= forward<T, S, PAIR, ROLLED>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0)).capped;
       const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3);   // B = [1/6 1/3 1/3 1/6]
       const T c = stage == 2 ? h : T(0.5) * h;                             // A = [.5; 0 .5; 0 0 1]
       static_for<0, S::NV>([&](auto II) { constexpr int i = II;
@@ -1131,7 +1279,7 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
     }
   } else {
     T rhs[S::NV];
-    capped |= forward<T, S, PAIR>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm).capped;
+    capped |= forward<T, S, PAIR, ROLLED>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm).capped;
     // (M + h*diag(damping)) a = qfrc_smooth + qfrc_constraint = M qacc
     sym_matvec<T, S>(M, acc, rhs);
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ; M[j + 2][j + 2] += h * G.damping[j]; });

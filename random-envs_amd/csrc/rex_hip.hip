@@ -282,6 +282,7 @@ __device__ __forceinline__ void planar_reset_lane(const DevState& s, const StepF
 // walker2d: the per-env model constants of lane i from its xi lengths (what build_model() does inside
 // RandomWalker2dEnv.set_task, random_walker2d.py:106-113)
 __device__ __forceinline__ void walker_derive_lane(const DevState& s, unsigned i, int refresh_frozen_masses);
+__device__ __attribute__((noinline)) void walker_derive_call(const DevState& s, unsigned i, int refresh_frozen_masses);
 // `resample` argument of the step kernel: bit 0 = set_random_task at reset, bit 1 = walker2d: re-derive the lane's geometry from its
 // new xi lengths right there (the auto-reset under DR used to cost a reset launch and a derive launch behind every step),
 // bit 2 = the Unmodeled id's frozen masses follow the new lengths
@@ -299,8 +300,11 @@ constexpr int RS_RESAMPLE = 1, RS_DERIVE = 2, RS_REFRESH = 4;
 // PAIR: two lanes per environment (lane 2i and 2i + 1 both hold env i; planar_spec.hpp "two lanes per environment"):
 // the launch has 2 B lanes in 64-lane blocks = 32 envs per wave, exactly the envs-per-wave of the 32-lane 1-lane-per-env
 // launch, but the wave is full and the per-slot work of the feet-only solver is split over the two lanes.
-template <class S, bool PAIR>
-__global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
+// ROLLED: the general solver instantiation as runtime loops over a row list in scratch (planar_engine.hpp::solve_newton_rolled): the kernel
+// then fits 256 registers and is built for TWO waves per SIMD -- hopper handles with more full one-lane-per-env waves than the GPU has SIMDs (rex_create).
+template <class S, bool PAIR, bool ROLLED = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLLED ? 2 : REX_STEP_WAVES, ROLLED ? 2 : REX_STEP_WAVES)))
+planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
                                                          SolParams<float> sp, const float* __restrict__ action,
                                                          float* __restrict__ obs, float* __restrict__ reward,
                                                          unsigned char* __restrict__ done_out,
@@ -329,7 +333,7 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
   float acc[S::NV];
   static_for<0, S::NV>([&](auto KK) { acc[KK] = 0.0f; });
 #pragma unroll 1
-  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S, PAIR>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
+  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S, PAIR, ROLLED>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
   if (PAIR && (threadIdx.x & 1u)) return;   // the even lane of a pair writes the results and runs the fused reset
   // the output addresses are formed from an opaque copy of the lane index: formed from `i`, the compiler computes all of them
   // next to the loads at the top, carries them through the solver, spills them and reloads each with a wait of its own
@@ -389,7 +393,12 @@ __global__ void __launch_bounds__(64) REX_STEP_OCC planar_step_kernel(DevState s
 #endif
   if (fused_reset && d) {
     planar_reset_lane<S>(s, fl, dr, resample & RS_RESAMPLE, 1, io, obs);
-    if constexpr (S::KIND == 3 && PAIR) { if (resample & RS_DERIVE) walker_derive_lane(s, io, (resample & RS_REFRESH) ? 1 : 0); }   // (one lane per env, REX_PAIR=0: the derive launch stays -- inlined there it spills)
+    if constexpr (S::KIND == 3) {
+      if (resample & RS_DERIVE) {
+        if constexpr (PAIR) walker_derive_lane(s, io, (resample & RS_REFRESH) ? 1 : 0);
+        else walker_derive_call(s, io, (resample & RS_REFRESH) ? 1 : 0);   // (one lane per env: inlined it spills the step's own state; as a call only this branch pays)
+      }
+    }
   }
 #if defined(REX_WAVETIME)
   if ((threadIdx.x & 63) == 0) { g_waveinfo[blockIdx.x & 8191][1] += __builtin_amdgcn_s_memtime() - tr0; }   // slot 1 ("iters", unused): cycles in the fused reset
@@ -475,8 +484,10 @@ __device__ __forceinline__ void walker_derive_lane(const DevState& s, unsigned i
   // masses 1..3 become the geometry-derived ones of the new lengths (random_walker2d_unmodeled.py:109-116)
   if (refresh_frozen_masses) for (int b = 0; b < 3; b++) (s.xi + (size_t)b * s.B)[i] = (float)nominal[b];
 }
+__device__ __attribute__((noinline)) void walker_derive_call(const DevState& s, unsigned i, int refresh_frozen_masses) { walker_derive_lane(s, i, refresh_frozen_masses); }
 #else
 __device__ __forceinline__ void walker_derive_lane(const DevState&, unsigned, int) {}
+__device__ __forceinline__ void walker_derive_call(const DevState&, unsigned, int) {}
 
 #endif
 
@@ -829,8 +840,9 @@ struct rex_env {
   float* d_scratch = nullptr;   // MAX_XI floats
   float* d_chol = nullptr;      // MAX_XI*MAX_XI floats (fullgaussian Cholesky factor)
   int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
-  int pair = 1;                 // planar chains: two lanes per env (REX_PAIR=0: one lane per env)
+  int pair = 1;                 // planar chains: two lanes per env up to 32 envs x SIMDs, one lane per env past that (REX_PAIR overrides)
   int hum_pair = 1;             // humanoid step: two lanes per env (humanoid_pair_step_kernel; REX_HUM_PAIR=0: one env per lane)
+  int rolled = 0;               // hopper, one lane per env: the 256-register step kernel (rolled general solver, two waves per SIMD); REX_ROLLED overrides
   int hum_fused_reset = 1;      // humanoid pair step: finished envs restart inside the step launch (REX_HUM_FUSED_RESET=0: the masked reset launch)
   int fused_derive = 1;         // walker2d: the auto-reset under DR re-derives the lane's geometry inside the step kernel (REX_FUSED_DERIVE=0: reset + derive launches)
   // timing: event pool created by rex_enable_timing, used as a ring by rex_step (no allocation in the step path)
@@ -913,14 +925,22 @@ static void host_derive(rex_env* h, PlanarGeom<float, S>& out, const double* siz
   for (int b = 0; b < S::NB; b++) h->nominal_xi[b] = (float)nominal[b];
 }
 
-// Lanes per workgroup (= per wavefront).  The step kernels are latency-bound (one wave per SIMD,
-// ~9 cycles per dependent VALU instruction against a 2-cycle issue), so what matters is the number
-// of resident WAVES, not the lanes each one fills: below 64 Ki envs a full-width launch leaves
-// SIMDs idle (32768 envs = 512 waves on 1024 SIMDs), half-filled waves put one on every SIMD.
-static int lanes_for(long long B) {
+// Launch shape by batch (rex_create; measured on MI355X, DESIGN.md section 6.1 "launch shape by batch").  The step kernels are latency-bound
+// (one wave per SIMD, ~9 cycles per dependent VALU instruction against a 2-cycle issue), so as long as the GPU has a SIMD for every wave what
+// matters is the time of ONE wave, and work is spread thin: two lanes per env (`pair`, 32 envs per wave) up to 32 envs x SIMDs (MI355X: 32 768 envs),
+// 32-lane blocks for the one-lane-per-env kernels.  Past that a SIMD has several waves to run one after the other and what matters is the work
+// per env: one lane per env in full 64-lane waves (the pair split costs 1.5-1.9x the instructions per env: cheetah 65 536 envs 309 -> 528 M
+// env-steps/s, hopper 419 -> 646 M, walker 157 -> 215 M), and for the hopper past 64 envs x SIMDs the 256-register kernel whose waves share a
+// SIMD two at a time (`rolled`: 2^20 envs 866 -> 1 422 M).  The humanoid stays on two lanes per env at every size (65 536 envs: 20.5 M against 13.4 M).
+static int simds_of(int device_id) {
+  int cus = 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 256;
+  return 4 * cus;
+}
+static int lanes_for(long long B, int simds) {
   const char* e = getenv("REX_LANES");
   if (e && atoi(e) > 0) return atoi(e);
-  return B >= 65536 ? 64 : 32;
+  return B > 32ll * simds ? 64 : 32;
 }
 // dynamic LDS of the humanoid kernels: one dual-PGS column (hum::DUAL_WORDS floats) per lane
 // (read once in rex_create and cached in the handle: grid, block and dynamic-LDS size always agree)
@@ -953,7 +973,8 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   rex_env* h = new (std::nothrow) rex_env();
   if (!h) return set_err(REX_ERR_ARG, "out of host memory");
   h->kind = env_kind; h->variant = variant; h->device = device_id; h->B = batch; h->env_offset = env_offset; h->seed = seed;
-  h->lanes = lanes_for(batch);
+  const int simds = simds_of(device_id);
+  h->lanes = lanes_for(batch, simds);
   if (h->lanes < 8 || h->lanes > 64 || (h->lanes & (h->lanes - 1))) { int l = h->lanes; delete h; return set_err(REX_ERR_ARG, "REX_LANES must be 8, 16, 32 or 64 (got %d)", l); }
   h->dims = dims;
   h->flags.endless = 0; h->flags.noisy = 0; h->flags.time_limit = 1; h->flags.max_steps = dims.max_episode_steps;
@@ -1037,14 +1058,19 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   if (getenv("REX_LS_FREE")) h->sp.ls_free = atoi(getenv("REX_LS_FREE"));
   if (getenv("REX_CORR")) h->sp.corr = atoi(getenv("REX_CORR"));
   if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
+  // launch shape by batch (lanes_for above has the measurements)
+  h->pair = batch <= 32ll * simds ? 1 : 0;
+  h->rolled = (env_kind == REX_HOPPER && batch > 64ll * simds) ? 1 : 0;
   if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
+  if (getenv("REX_ROLLED")) h->rolled = (env_kind == REX_HOPPER && atoi(getenv("REX_ROLLED"))) ? 1 : 0;
   if (getenv("REX_HUM_PAIR")) h->hum_pair = atoi(getenv("REX_HUM_PAIR")) ? 1 : 0;
   if (getenv("REX_HUM_FUSED_RESET")) h->hum_fused_reset = atoi(getenv("REX_HUM_FUSED_RESET")) ? 1 : 0;
-  // walker2d: derive fused into the step kernel while the step is launch-latency bound (32 768 envs: + 10 % env-steps/s); from ~2^18 envs up
-  // the two small launches cost less than the derive does inside the step kernel's waves (2^20 envs: 238 M against 234 M env-steps/s)
-  h->fused_derive = batch < 262144 ? 1 : 0;
+  // walker2d: derive fused into the step kernel (inlined in the pair kernel, a call in the one-lane one) while the two small launches behind a
+  // step are a visible share of it (32 768 envs: + 10 % env-steps/s, 65 536: + 9 %, 131 072: + 4.5 %, 2^20: - 0.5 %)
+  h->fused_derive = batch < 524288 ? 1 : 0;
   if (getenv("REX_FUSED_DERIVE")) h->fused_derive = atoi(getenv("REX_FUSED_DERIVE")) ? 1 : 0;
   if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
+  if (h->pair) h->rolled = 0;     // the two-waves-per-SIMD kernel is a one-lane-per-env one
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, 0, d.xi, h->d_scratch, full.task_dim, (long long)B);
@@ -1178,6 +1204,13 @@ static void launch_planar_step(rex_env* h, const DevState& dev, const StepFlags&
     hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(64), 0, st, dev, flags, geom, h->sp, action, obs_out, reward_out,
                        done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
   } else {
+    if constexpr (S::KIND == 1) {
+      if (h->rolled) {   // two waves per SIMD (rex_create: more full waves than SIMDs)
+        hipLaunchKernelGGL((planar_step_kernel<S, false, true>), dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, flags, geom, h->sp, action, obs_out,
+                           reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
+        return;
+      }
+    }
     hipLaunchKernelGGL((planar_step_kernel<S, false>), dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, flags, geom, h->sp, action, obs_out,
                        reward_out, done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
   }
@@ -1207,10 +1240,10 @@ extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* rew
   const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
   // planar envs reset finished lanes inside the step kernel (walker2d under DR re-derives the lane's geometry there as well)
   const bool walker_dr = h->kind == REX_WALKER2D && resample_on_reset && h->dr.type != REX_DR_NONE;
-  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || (h->pair && h->fused_derive))) ||
+  const int fused = (h->autoreset && (h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || (h->kind == REX_WALKER2D && (!walker_dr || h->fused_derive)) ||
                                       (h->kind == REX_HUMANOID && h->hum_pair && h->hum_fused_reset))) ? 1 : 0;
   int rs = resample_on_reset ? RS_RESAMPLE : 0;
-  if (walker_dr && h->pair && h->fused_derive) rs |= RS_DERIVE | (h->variant ? RS_REFRESH : 0);
+  if (walker_dr && h->fused_derive) rs |= RS_DERIVE | (h->variant ? RS_REFRESH : 0);
   // every `timing`-th launch is bracketed by two events of the pool rex_enable_timing created (ring): the two event packets
   // cost ~8 us of stream time per launch, 9 % of a hopper step, so a throughput run samples (bench.py: every 8th launch)
   const bool timed = h->timing > 0 && (h->launches++ % (unsigned long long)h->timing) == 0;

@@ -26,7 +26,8 @@ def shard(batch_per_rank, rank):
     return rank * batch_per_rank, batch_per_rank
 
 
-WAVE_ENVS = 32   # envs per wavefront of the step kernels: the solver instantiation is picked per wave
+WAVE_ENVS = 64   # envs per wavefront of the step kernels at their widest (one lane per env, past 32 768 envs per GPU; 32 with two lanes per env):
+                 # the solver instantiation is picked per wave
 
 
 def shard_strong(global_batch, rank, world, align=WAVE_ENVS):

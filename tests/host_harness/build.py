@@ -52,6 +52,12 @@ def set_fast(flag):
     lib().ph_set_fast(int(flag))
 
 
+def set_rolled(flag):
+    """1 = the general path as the rolled row-list solver (planar_engine.hpp::solve_newton_rolled: what the 256-register hopper kernel of
+    handles with >= 65 536 envs runs), 0 = the unrolled per-slot instantiation"""
+    lib().ph_set_rolled(int(flag))
+
+
 def set_line_search(ls_max=-1, ls_free=-1):
     """override SolParams.ls_max / ls_free of the following calls (-1: the model's defaults)"""
     lib().ph_set_ls(int(ls_max), int(ls_free))

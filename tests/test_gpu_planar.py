@@ -84,12 +84,17 @@ def test_step_parity_on_rollout_states(torch_mod, kind, lanes):
     env.close()
 
 
-@pytest.mark.parametrize("knobs", [dict(REX_PAIR=0), dict(REX_CORR=0), dict(REX_FAST=0), dict(REX_PAIR=0, REX_CORR=0, REX_LS_FREE=0, REX_LS_MAX=3)])
+@pytest.mark.parametrize("knobs", [dict(REX_PAIR=0), dict(REX_CORR=0), dict(REX_FAST=0), dict(REX_PAIR=0, REX_CORR=0, REX_LS_FREE=0, REX_LS_MAX=3),
+                                   dict(REX_ROLLED=1, REX_PAIR=0), dict(REX_ROLLED=1, REX_FAST=0)])
 @pytest.mark.parametrize("kind", ["hopper", "walker2d", "halfcheetah"])
 def test_every_solver_configuration_matches_the_oracle(torch_mod, kind, knobs):
     """The solver's machinery is switchable at create time (REX_PAIR: two lanes per env, REX_CORR: one-group correction,
-    REX_FAST: feet-only instantiation + qacc_smooth skip, REX_LS_FREE / REX_LS_MAX: line-search schedule).  Every
+    REX_FAST: feet-only instantiation + qacc_smooth skip, REX_LS_FREE / REX_LS_MAX: line-search schedule, REX_ROLLED (with one lane per env): the
+    hopper's 256-register / two-waves-per-SIMD step kernel with the rolled general solver, the default past 65 536 envs -- with REX_FAST=0 every
+    evaluation of every lane goes through the rolled solver).  Every
     configuration reaches the same unique minimiser: each one against the oracle, every lane, same tolerances."""
+    if "REX_ROLLED" in knobs and kind != "hopper":
+        pytest.skip("the rolled step kernel is the hopper's")
     import random_envs_amd as rex
     from oracle_bindings import DIMS, oracle_batch_step, rollout_states
     from parity_util import create_knobs
@@ -108,9 +113,13 @@ def test_every_solver_configuration_matches_the_oracle(torch_mod, kind, knobs):
     env.close()
 
 
-def test_hopper_contact_rich_and_limit_states(torch_mod):
-    """random (not rollout) states: deeper penetrations, joint limits violated, large velocities"""
+@pytest.mark.parametrize("rolled", [0, 1])
+def test_hopper_contact_rich_and_limit_states(torch_mod, rolled):
+    """random (not rollout) states: deeper penetrations, joint limits violated, large velocities -- practically every wave leaves the
+    feet-only path, so this is the test of the general solver: the unrolled per-slot one (rolled = 0, the kernels up to 65 536 envs) and the
+    rolled row-list one of the two-waves-per-SIMD kernel (rolled = 1, one lane per env)"""
     import random_envs_amd as rex
+    from parity_util import create_knobs
     from oracle_bindings import oracle_batch_step
     from random_envs_amd.specs import SPECS
     n = 4096; rng = np.random.RandomState(7)
@@ -118,7 +127,8 @@ def test_hopper_contact_rich_and_limit_states(torch_mod):
     q = rng.uniform(-0.4, 0.4, (n, 6)); q[:, 1] = rng.uniform(1.05, 1.4, n); q[:, 5] = rng.uniform(-0.9, 0.9, n)
     v = rng.uniform(-3, 3, (n, 6)); a = rng.uniform(-1.2, 1.2, (n, 3))
     q, v, xi, a = [x.astype(np.float32).astype(np.float64) for x in (q, v, xi, a)]
-    env = rex.make("RandomHopper-v0", batch=n, autoreset=False)
+    with create_knobs(REX_ROLLED=rolled, REX_PAIR=(0 if rolled else None)):
+        env = rex.make("RandomHopper-v0", batch=n, autoreset=False)
     obs, r, dn, qq, vv = _step_from(env, torch_mod, q, v, xi, a)
     ref = oracle_batch_step("hopper", q, v, a, xi)
     vs = 1 + np.abs(ref["qvel"]).max(1)

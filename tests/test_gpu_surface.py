@@ -26,15 +26,17 @@ def _dr_oracle():
 
 
 # ------------------------------------------------------------------------------------------------- 64-lane blocks
-@pytest.mark.parametrize("kind,eid", [("hopper", "RandomHopper-v0"), ("walker2d", "RandomWalker2d-v0")])
-def test_step_parity_at_65536_envs(torch_mod, kind, eid):
-    """The launch shape rex picks by itself from 65 536 envs up (64-lane blocks): 2 048 oracle-checked states tiled over
-    the batch, every copy bit-identical to the first (lane position must not matter) and the first within tolerance."""
+@pytest.mark.parametrize("kind,eid,B", [("hopper", "RandomHopper-v0", 65536), ("walker2d", "RandomWalker2d-v0", 65536), ("halfcheetah", "RandomHalfCheetah-v0", 40960),
+                                        ("hopper", "RandomHopper-v0", 131072)])
+def test_step_parity_at_65536_envs(torch_mod, kind, eid, B):
+    """The launch shapes rex picks by itself past 32 768 envs (one lane per env in 64-lane blocks; hopper past 65 536 envs: the 256-register
+    kernel, two waves per SIMD): 2 048 oracle-checked states tiled over the batch, every copy bit-identical to the first (lane position must
+    not matter) and the first within tolerance."""
     import random_envs_amd as rex
     from oracle_bindings import DIMS, oracle_batch_step, oracle_sensitivity, rollout_states
     from parity_util import assert_lanes_explained
     torch = torch_mod
-    n, B = 2048, 65536; d = DIMS[kind]
+    n = 2048; d = DIMS[kind]
     q, v, xi = rollout_states(kind, n, steps_max=60, seed=21)
     q, v, xi = [x.astype(np.float32).astype(np.float64) for x in (q, v, xi)]
     a = np.random.RandomState(6).uniform(-1, 1, (n, d["nu"])).astype(np.float32).astype(np.float64)
@@ -48,8 +50,8 @@ def test_step_parity_at_65536_envs(torch_mod, kind, eid):
         assert np.array_equal(qq[k * n:(k + 1) * n], qq[:n]) and np.array_equal(vv[k * n:(k + 1) * n], vv[:n])
     ref, sens = oracle_sensitivity(lambda q_, v_, a_, x_: oracle_batch_step(kind, q_, v_, a_, x_), [q, v, a, xi], ["qpos", "qvel"])
     vs = 1 + np.abs(ref["qvel"]).max(1)
-    assert_lanes_explained(np.abs(qq[:n] - ref["qpos"]).max(1), sens["qpos"], 2e-5, 5e-4, label=kind + " B=65536 |dqpos|")
-    assert_lanes_explained(np.abs(vv[:n] - ref["qvel"]).max(1) / vs, sens["qvel"] / vs, 2e-4, 2e-2, label=kind + " B=65536 |dqvel|rel")
+    assert_lanes_explained(np.abs(qq[:n] - ref["qpos"]).max(1), sens["qpos"], 2e-5, 5e-4, label=kind + " B=%d |dqpos|" % B)
+    assert_lanes_explained(np.abs(vv[:n] - ref["qvel"]).max(1) / vs, sens["qvel"] / vs, 2e-4, 2e-2, label=kind + " B=%d |dqvel|rel" % B)
     env.close()
 
 

@@ -4,7 +4,7 @@ reduction itself, fp32 instantiation gives the tolerance the GPU tests use."""
 import numpy as np
 import pytest
 
-from host_harness.build import host_constants, host_forward, host_step, last_mode, set_fast, set_line_search
+from host_harness.build import host_constants, host_forward, host_step, last_mode, set_fast, set_line_search, set_rolled
 from oracle_bindings import (DIMS, oracle_batch_step, oracle_constants, oracle_contacts, oracle_forward,
                              rollout_states)
 from random_envs_amd.specs import SPECS
@@ -125,6 +125,58 @@ def test_fast_and_general_solver_instantiations_agree(kind):
     assert modes[3] > 30, modes
     e32 = np.abs(v32f - v32g).max(1) / (1 + np.abs(v32g).max(1))
     assert np.percentile(e32, 99) < 2e-4 and np.abs(q32f - q32g).max() < 2e-5
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_rolled_general_solver_matches_the_unrolled_one_and_the_oracle(kind):
+    """solve_newton_rolled (the general path of the 256-register hopper kernel: runtime loops over a row list) is the same Newton method on
+    the same rows as the unrolled per-slot solver: same minimiser in fp64 (both against the oracle too), fp32 tolerance in fp32.  Run with the
+    feet-only path switched off so that EVERY evaluation goes through it, and on the self-collision states with it on."""
+    d = DIMS[kind]
+    q, v, xi = rollout_states(kind, 300, steps_max=50, seed=11)
+    a = np.random.RandomState(5).uniform(-1, 1, (300, d["nu"]))
+    ref = oracle_batch_step(kind, q, v, a, xi)
+    try:
+        set_fast(0)
+        set_rolled(0); qu, vu, _ = host_step(kind, False, q, v, a, xi, d["frame_skip"])
+        set_rolled(1); qr, vr, cap = host_step(kind, False, q, v, a, xi, d["frame_skip"]); q32, v32, cap32 = host_step(kind, True, q, v, a, xi, d["frame_skip"])
+        set_fast(1); qf, vf, _ = host_step(kind, False, q, v, a, xi, d["frame_skip"])
+        modes = set()
+        for i in range(0, 300, 5):
+            set_fast(0); qa, _, _ = host_forward(kind, False, q[i], v[i], a[i], xi[i]); modes.add(last_mode())
+            o = oracle_forward(kind, q[i], v[i], a[i], xi[i])
+            assert np.abs(qa - o["qacc"]).max() / (1 + np.abs(o["qacc"]).max()) < 1e-6
+    finally:
+        set_rolled(0); set_fast(1)
+    assert cap.sum() == 0 and cap32.sum() == 0
+    assert modes <= {0, 1, 2} and (1 in modes or 2 in modes), modes
+    e = np.abs(vr - vu).max(1) / (1 + np.abs(vu).max(1))
+    assert e.max() < 1e-9 and np.abs(qr - qu).max() < 1e-11, (e.max(), np.abs(qr - qu).max())
+    assert np.abs(qf - qr).max() < 1e-11
+    e64 = np.abs(vr - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    assert np.percentile(e64, 99) < 1e-7
+    eq = np.abs(q32 - ref["qpos"]).max(1); ev = np.abs(v32 - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    assert np.percentile(eq, 99) < 2e-5 and np.percentile(ev, 99) < 2e-4, (eq.max(), ev.max())
+
+
+def test_rolled_solver_on_hopper_self_collision_rows():
+    """the row list carries the capsule-capsule rows (mode 2) as well"""
+    xi = np.array(SPECS["hopper"].nominal_task); rng = np.random.RandomState(3); hits = 0
+    try:
+        set_rolled(1)
+        for _ in range(1500):
+            q = np.array([0, rng.uniform(1.2, 1.6), rng.uniform(-.3, .3), rng.uniform(-2.6, -1.5), rng.uniform(-2.6, -1.5), rng.uniform(-.8, .8)])
+            v = rng.uniform(-1, 1, 6); a = rng.uniform(-1, 1, 3)
+            con = oracle_contacts("hopper", q, v, xi); self_con = con[con[:, 0] > 0]
+            if len(self_con) == 0 or self_con[:, 2].min() < -0.07:
+                continue
+            o = oracle_forward("hopper", q, v, a, xi); qa, _, _ = host_forward("hopper", False, q, v, a, xi)
+            assert last_mode() == 2
+            assert np.abs(qa - o["qacc"]).max() / (1 + np.abs(o["qacc"]).max()) < 1e-7
+            hits += 1
+    finally:
+        set_rolled(0)
+    assert hits > 10
 
 
 @pytest.mark.parametrize("kind", KINDS)
