@@ -43,7 +43,7 @@ def assert_done_explained(done_gpu, done_ref, margins, eps, label=""):
 @contextlib.contextmanager
 def lanes_per_block(n):
     """Launch shape of the handles created inside: REX_LANES is read once in rex_create (None = the default rule:
-    32-lane blocks below 65 536 envs, 64-lane blocks -- and the > 64 KB dynamic-LDS opt-in of the humanoid -- above)."""
+    32-lane blocks up to 32 768 envs, 64-lane blocks -- and the > 64 KB dynamic-LDS opt-in of the humanoid's one-lane kernels -- past that)."""
     old = os.environ.get("REX_LANES")
     try:
         if n is None:

@@ -32,7 +32,7 @@ TOL_REW, CAP_REW = 2e-3, 2e-1
 @pytest.mark.parametrize("lanes", [None, 64])
 def test_step_parity_and_second_step(torch_mod, lanes):
     """Every lane within tolerance or explained by the oracle's own conditioning; default launch shape and 64-lane blocks
-    (the > 64 KB dynamic-LDS configuration rex uses from 65 536 envs up)."""
+    (the > 64 KB dynamic-LDS configuration rex uses past 32 768 envs)."""
     import random_envs_amd as rex
     from oracle_bindings import oracle_humanoid_step, oracle_sensitivity
     from parity_util import assert_done_explained, assert_lanes_explained, lanes_per_block

@@ -48,7 +48,7 @@ TOL_REWARD, CAP_REWARD = 5e-3, 1e-1
 @pytest.mark.parametrize("kind", ["hopper", "walker2d", "halfcheetah"])
 def test_step_parity_on_rollout_states(torch_mod, kind, lanes):
     """Every lane within the stated fp32 tolerance of the oracle, or explained by the oracle's own ill-conditioning;
-    once with the default launch shape and once with 64-lane blocks (the shape rex uses from 65 536 envs up)."""
+    once with the default launch shape and once with 64-lane blocks (the shape rex uses past 32 768 envs)."""
     import random_envs_amd as rex
     from oracle_bindings import DIMS, oracle_batch_step, oracle_sensitivity, rollout_states
     from parity_util import assert_done_explained, assert_lanes_explained, lanes_per_block

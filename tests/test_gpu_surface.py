@@ -1,5 +1,5 @@
 """The rest of the drop-in surface on the GPU, each item against the oracle or a reference-stated rule:
-the 64-lane launch shape at a real >= 65 536 batch, device xi draws vs oracle/dr_sampler.py (two-sample KS, all four
+the launch shapes rex picks past 32 768 envs at real batches of that size, device xi draws vs oracle/dr_sampler.py (two-sample KS, all four
 dr_types), observation noise of the Noisy ids, per-term reward `info`, RNG-exact / time-limit-exact resume, the
 offline-replay helpers for every chain, lane export for a viewer, `dt`, side-effect-free sample_tasks."""
 import os
