@@ -983,9 +983,11 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
 // runtime-indexed local arrays (scratch on the device) and walked by runtime loops.  Far slower per solve than the unrolled general
 // instantiation, and far smaller in registers: for a chain whose batches practically never leave the feet-only path (the hopper: 100 % of
 // the wave-solves under a random policy) the kernel's register allocation is then the feet-only path's own -- 256 VGPRs, no AGPR --, so TWO
-// waves share a SIMD and fill each other's issue slots.  That pays as soon as some SIMD has two waves to run: above 32 768 envs per GPU
-// (34 816 envs: 261 -> 296 M env-steps/s, 2^20: 519 -> 904 M); up to 32 768 envs every wave has a SIMD to itself and the feet-only path is
-// 5-20 % slower on 256 registers than on 461, so those batches keep the unrolled general instantiation (rex_hip.hip picks per handle).
+// waves share a SIMD and fill each other's issue slots.  That pays where a SIMD has waves queued: the one-lane-per-env hopper kernel past
+// 65 536 envs per GPU (131 072 envs: 709 -> 777 M env-steps/s, 2^20: 866 -> 1 422 M).  While every wave has a SIMD to itself the feet-only path
+// is 5-20 % slower on 256 registers than on 458, and a solve that does take this path costs several times the unrolled one (dependent scratch
+// reads per row and pass), which at one wave per SIMD is what the launch then waits for: those batches keep the unrolled general
+// instantiation (rex_hip.hip: rex_create picks per handle).
 template <class T, class S>
 struct RowList {
   static constexpr int MAXR = (S::NB - 1) + 3 * 2 * S::NG + (S::NSELF > 0 ? 2 * S::NSELF : 0);
