@@ -148,9 +148,10 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/collect.sh writes
-    profiles/hbm_traffic.json together with the digest of the sources it profiled).  Returns (bytes or None, stale)."""
+def pmc_traffic(key, batch, kernel):
+    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (profiles/collect_cfg.sh + summarise_cfg.py write
+    profiles/hbm_traffic.json together with the digest of the sources, the per-GPU batch and the kernel they profiled).  Returns (bytes or
+    None, stale): a figure is reported only for the sources, batch and kernel instantiation it was measured on."""
     tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(tp):
         return None, False
@@ -158,9 +159,10 @@ def pmc_traffic(key):
         rec = json.load(open(tp))
     except Exception:
         return None, False
-    rec = rec.get(key, rec if key == ENV_ID else {})
-    if not rec or "bytes_per_launch" not in rec:
-        return None, False
+    rec = next((r for r in (rec.get(key), rec.get("%s@%d" % (key, batch)))
+                if isinstance(r, dict) and "bytes_per_launch" in r and r.get("batch", batch) == batch and r.get("kernel", kernel) == kernel), None)
+    if rec is None:
+        return None, False         # nothing measured at this batch / launch shape
     if rec.get("source_digest") != source_digest():
         return None, True          # kernels changed since the PMC run: do not report a stale figure
     return rec["bytes_per_launch"], False
@@ -331,7 +333,7 @@ def main():
         achieved = bytes_step * B / (kavg_ms * 1e-3) / 1e9 if kavg_ms == kavg_ms else None
         wall_ms = 1e3 * elapsed / args.steps
         achieved_wall = bytes_step * B / (wall_ms * 1e-3) / 1e9
-        traffic, stale = pmc_traffic(args.config or env_id) if not args.replay else (None, False)
+        traffic, stale = pmc_traffic(args.config or env_id, B, kernel_of(kind, B)) if not args.replay else (None, False)
         out = {
             "metric": METRIC, "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_ms,

@@ -57,7 +57,7 @@ try:
 except Exception:
     rec = {}
 if traffic is not None:
-    rec[key] = {"kernel": kname, "bytes_per_launch": traffic, "source_digest": bench.source_digest(),
+    rec[key] = {"kernel": kname, "batch": int(line["config"]["global_batch"]) // max(int(line["n_gpus"]), 1), "bytes_per_launch": traffic, "source_digest": bench.source_digest(),
                 "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag}
     json.dump(rec, open(tp, "w"), indent=1)
 cp = os.path.join(ROOT, "profiles", "r03_configs.json")
