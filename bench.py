@@ -39,17 +39,15 @@ BYTES_PER_KIND = {"hopper": 173, "walker2d": 293, "halfcheetah": 273, "cartpole"
 PLANAR_SPEC = {"hopper": "HopperSpec", "walker2d": "Walker2dSpec", "halfcheetah": "HalfCheetahSpec"}
 
 
-def kernel_of(kind, batch):
-    """rex_create's launch shape by batch (rex_hip.hip, on MI355X's 1 024 SIMDs): planar chains run two lanes per env up to 32 768 envs and one
-    lane per env past that; the hopper past 65 536 envs launches the 256-register / two-waves-per-SIMD kernel with the rolled general solver
-    (REX_PAIR / REX_ROLLED / REX_FAST override)."""
+def kernel_of(kind, shape):
+    """Name of the step kernel a handle launches, from the launch shape rex_create picked for it (VecRandomEnv.launch_shape(): planar chains two
+    lanes per env up to 32 envs x SIMDs and one lane per env past that, the hopper past 64 envs x SIMDs on the 256-register kernel with the
+    rolled general solver)."""
     if kind == "cartpole":
         return "cartpole_step_kernel"
     if kind == "humanoid":
-        return "humanoid_pair_step_kernel" if int(os.environ.get("REX_HUM_PAIR", "1")) else "humanoid_step_kernel"
-    pair = (int(os.environ["REX_PAIR"]) != 0 if "REX_PAIR" in os.environ else batch <= 32768) and int(os.environ.get("REX_FAST", "1")) != 0
-    rolled = kind == "hopper" and not pair and (int(os.environ["REX_ROLLED"]) != 0 if "REX_ROLLED" in os.environ else batch > 65536)
-    return "planar_step_kernel<rex::%s, %s, %s>" % (PLANAR_SPEC[kind], "true" if pair else "false", "true" if rolled else "false")
+        return "humanoid_pair_step_kernel" if shape["hum_pair"] else "humanoid_step_kernel"
+    return "planar_step_kernel<rex::%s, %s, %s>" % (PLANAR_SPEC[kind], "true" if shape["pair"] else "false", "true" if shape["rolled"] else "false")
 
 
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
@@ -322,6 +320,7 @@ def main():
     total_steps = counter.total()
     elapsed = sharding.reduce_max(elapsed, cdev)
     counters = env.counters()
+    shape = env.launch_shape()
 
     if rank == 0:
         value = total_steps / elapsed
@@ -333,7 +332,7 @@ def main():
         achieved = bytes_step * B / (kavg_ms * 1e-3) / 1e9 if kavg_ms == kavg_ms else None
         wall_ms = 1e3 * elapsed / args.steps
         achieved_wall = bytes_step * B / (wall_ms * 1e-3) / 1e9
-        traffic, stale = pmc_traffic(args.config or env_id, B, kernel_of(kind, B)) if not args.replay else (None, False)
+        traffic, stale = pmc_traffic(args.config or env_id, B, kernel_of(kind, shape)) if not args.replay else (None, False)
         out = {
             "metric": METRIC, "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_ms,
@@ -347,7 +346,7 @@ def main():
                                       "asynchronously every %d steps" % (world, args.scaling, args.counter_every)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": kernel_of(kind, B), "kernel_avg_ms": kavg_ms, "kernel_launches_timed": len(kernel_ms_ext),
+                         "kernel": kernel_of(kind, shape), "launch_shape": shape, "kernel_avg_ms": kavg_ms, "kernel_launches_timed": len(kernel_ms_ext),
                          "kernel_launches_timed_in_region": n_k, "kernel_avg_ms_in_region": kavg_region if n_k else None,
                          "algorithmic_bytes_per_launch": bytes_step * B, "bytes_per_env_step": bytes_step,
                          # the same fraction on the WALL clock of the timed region (what `value` is computed from)

@@ -174,6 +174,13 @@ int64_t rex_step_count(const rex_t* h);
  * [2] constraint solves that hit the iteration cap. Copies 4 int64 to `out` [host]; synchronises. */
 int rex_get_counters(rex_t* h, int64_t* out);
 
+/* the launch shape rex_create picked for this handle from its batch and the GPU's SIMD count (the REX_LANES / REX_PAIR /
+ * REX_ROLLED / REX_HUM_PAIR knobs override): out[0] lanes per workgroup of the one-lane-per-env launches, out[1] 1 = the planar step runs
+ * two lanes per env, out[2] 1 = hopper step on the 256-register kernel with the rolled general solver (two waves per SIMD), out[3] 1 = the
+ * humanoid step runs two lanes per env.  No reference counterpart (the reference steps one MjSim on one core); bench.py names the launched
+ * kernel from it.  Writes 4 int32 to `out` [host]. */
+int rex_get_launch_shape(const rex_t* h, int32_t* out);
+
 /* duration in ms of the sampled rex_step kernel launches since the last enable / read (at most the last 8192), measured
  * with HIP events on the launch stream; returns the number of samples written.  The two event packets of a bracketed launch
  * cost about 8 us of stream time, so throughput runs sample every n-th launch.  rex_enable_timing(1) creates

@@ -1424,6 +1424,13 @@ extern "C" int rex_get_counters(rex_t* h, int64_t* out) {
   HIP_TRY(hipMemcpy(out, h->dev.counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost));
   return REX_OK;
 }
+extern "C" int rex_get_launch_shape(const rex_t* h, int32_t* out) {
+  if (!h || !out) return set_err(REX_ERR_ARG, "rex_get_launch_shape: null argument");
+  const bool planar = h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || h->kind == REX_WALKER2D;
+  out[0] = h->lanes; out[1] = (planar && h->pair) ? 1 : 0; out[2] = (h->kind == REX_HOPPER && !h->pair && h->rolled) ? 1 : 0;
+  out[3] = (h->kind == REX_HUMANOID && h->hum_pair) ? 1 : 0;
+  return REX_OK;
+}
 extern "C" int rex_enable_timing(rex_t* h, int enable) {
   if (!h) return set_err(REX_ERR_ARG, "null handle");
   if (enable && h->ev0.empty()) {   // the only place events are created: rex_step never allocates

@@ -411,6 +411,12 @@ class VecRandomEnv(DRConfig):
         _native.check(self._L.rex_get_counters(self._h, out))
         return dict(nonfinite=out[0], gaussian_fail=out[1], solver_capped=out[2], overflow=out[3])
 
+    def launch_shape(self):
+        """What rex_create picked for this handle from its batch and the GPU's SIMD count."""
+        out = (ctypes.c_int32 * 4)()
+        _native.check(self._L.rex_get_launch_shape(self._h, out))
+        return dict(lanes=int(out[0]), pair=bool(out[1]), rolled=bool(out[2]), hum_pair=bool(out[3]))
+
     def enable_timing(self, every=1):
         """HIP-event duration of every `every`-th step kernel launch (True / 1: all of them, 0 / False: off)."""
         _native.check(self._L.rex_enable_timing(self._h, int(every)))

@@ -154,3 +154,33 @@ def test_sb3_style_adapter(torch_mod):
             seen += 1
     assert seen > 0 and venv.get_attr("task_dim") == [4] * 128 and venv.get_attr("task_dim", indices=[0]) == [4]
     venv.close()
+
+
+def test_launch_shape_follows_the_batch(torch_mod):
+    """rex_get_launch_shape: what rex_create picks from the per-GPU batch and the GPU's SIMD count -- planar chains two lanes
+    per env while 32 envs x SIMDs hold the batch, one lane per env in 64-lane blocks past that, the hopper past 64 envs x SIMDs on the rolled
+    two-waves-per-SIMD kernel; the humanoid on two lanes per env everywhere; knobs override."""
+    import random_envs_amd as rex
+    from parity_util import create_knobs
+    simds = 4 * torch_mod.cuda.get_device_properties(0).multi_processor_count
+    for eid, hopper in (("RandomHopper-v0", True), ("RandomWalker2d-v0", False), ("RandomHalfCheetah-v0", False)):
+        for B, want in ((1, (32, True, False)), (32 * simds, (32, True, False)), (32 * simds + 1, (64, False, False)),
+                        (64 * simds, (64, False, False)), (64 * simds + 1, (64, False, hopper))):
+            env = rex.make(eid, batch=B, autoreset=False)
+            sh = env.launch_shape()
+            assert (sh["lanes"], sh["pair"], sh["rolled"]) == want and not sh["hum_pair"], (eid, B, sh)
+            env.close()
+    env = rex.make("RandomHumanoid-v0", batch=64, autoreset=False)
+    assert env.launch_shape()["hum_pair"] and not env.launch_shape()["pair"]
+    env.close()
+    with create_knobs(REX_PAIR=0, REX_ROLLED=1, REX_LANES=64):
+        env = rex.make("RandomHopper-v0", batch=256, autoreset=False)
+    assert env.launch_shape() == dict(lanes=64, pair=False, rolled=True, hum_pair=False)
+    env.close()
+    with create_knobs(REX_FAST=0):   # the pair split lives in the feet-only instantiation
+        env = rex.make("RandomHopper-v0", batch=256, autoreset=False)
+    assert not env.launch_shape()["pair"]
+    env.close()
+    env = rex.make("RandomCartPole-v0", batch=256, autoreset=False)
+    assert env.launch_shape() == dict(lanes=32, pair=False, rolled=False, hum_pair=False)
+    env.close()

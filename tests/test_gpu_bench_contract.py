@@ -36,6 +36,29 @@ def test_headline_line_contract():
     assert d["nonfinite_lanes"] == 0 and d["solver_capped_waves"] == 0
 
 
+def test_line_names_the_launched_kernel_and_its_own_traffic_figure():
+    """roofline.kernel follows the launch shape of the handle (rex_get_launch_shape), and roofline.traffic is reported only from a PMC record of
+    the same batch, kernel instantiation and sources (profiles/hbm_traffic.json) -- never the 32 768-env figure next to another batch."""
+    import random_envs_amd  # noqa: F401  (bench imports the package the same way)
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    d = _run("--steps", "24", "--warmup", "4", "--batch", "49152", "--no-cpu-baseline")
+    r = d["roofline"]
+    assert r["launch_shape"] == dict(lanes=64, pair=False, rolled=False, hum_pair=False) and r["kernel"] == "planar_step_kernel<rex::HopperSpec, false, false>"
+    assert r["traffic"] is None
+    d = _run("--steps", "24", "--warmup", "4", "--batch", "131072", "--no-cpu-baseline")
+    assert d["roofline"]["launch_shape"]["rolled"] and d["roofline"]["kernel"] == "planar_step_kernel<rex::HopperSpec, false, true>"
+    d = _run("--steps", "24", "--warmup", "4", "--no-cpu-baseline")
+    r = d["roofline"]
+    assert r["launch_shape"]["pair"] and r["kernel"] == "planar_step_kernel<rex::HopperSpec, true, false>"
+    e = rec["RandomHopper-v0"]
+    if e["source_digest"] == bench.source_digest():
+        assert e["batch"] == 32768 and e["kernel"] == r["kernel"] and r["traffic"] == e["bytes_per_launch"]
+    else:
+        assert r["traffic"] is None
+
+
 def test_humanoid_line():
     d = _run("--env", "RandomHumanoid-v0", "--steps", "12", "--warmup", "3", "--batch", "2048", "--no-cpu-baseline")
     assert "RandomHumanoid-v0" in d["config"]["workload"] and d["value"] > 1e5
