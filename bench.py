@@ -10,9 +10,10 @@ Actions, state and xi are resident in HBM before the timed region starts.  The e
 (weak scaling: 32768 envs per GPU); the ONLY collective is the all-reduce of the step counter (plus the
 max-over-ranks of the elapsed time required by the contract).
 
-`--config C2|C3|C4|C5` selects the other BASELINE.json configurations with SURVEY.md section 8(d)'s inputs
+`--config C1|C2|C3|C4|C5` selects the other BASELINE.json configurations with SURVEY.md section 8(d)'s inputs
 (per-GPU shard of the config, its env id, its DR distribution); without it the north-star point (hopper,
-32768 envs per GPU, uniform xi nominal +-10 %) runs.
+32768 envs per GPU, uniform xi nominal +-10 %) runs.  `metric` is BASELINE.json's string on the north-star line only;
+every other line names its own quantity (env id, batch, GPUs) there.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel, from HIP-event durations of launches of the timed region,
@@ -51,10 +52,25 @@ def kernel_of(kind, shape):
 
 
 METRIC = "env-steps/sec at batch 32768, RandomHopper-v0, 1/2/4/8 MI355X; % HBM roofline"   # BASELINE.json
+
+
+def metric_of(env_id, batch_per_gpu, global_batch, world, scaling, replay=False):
+    """The `metric` string of a line: BASELINE.json's on the line that measures it (RandomHopper-v0 at 32 768 envs -- per GPU under weak
+    scaling, in total under strong scaling: SURVEY.md 8(d)), the line's own quantity everywhere else."""
+    headline = env_id == ENV_ID and not replay and (batch_per_gpu if scaling == "weak" else global_batch) == BATCH_PER_GPU
+    if headline:
+        return METRIC
+    what = "replayed env-steps/sec" if replay else "env-steps/sec"
+    return "%s at batch %d%s, %s, %d MI355X; %% HBM roofline" % (what, global_batch if scaling == "strong" else batch_per_gpu,
+                                                                  " in total" if scaling == "strong" and world > 1 else (" per GPU" if world > 1 else ""),
+                                                                  env_id, world)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # BASELINE.json configs[1..4] with SURVEY.md section 8(d)'s synthetic inputs; `batch` is the per-GPU shard
 CONFIGS = {
+    "C1": dict(env="RandomCartPole-v0", batch=1, dr="none",
+               note="batch 1, actions ~ U{0,1}, reset on done, no DR (test_random_policy.py:12-32): plumbing -- one env is one lane of one wave, "
+                    "the line is the launch latency of a step"),
     "C2": dict(env="RandomHopper-v0", batch=4096, dr="readme",
                note="uniform xi, distr [0.9,1.1,1.9,2.1,2.9,3.1,3.9,4.1] (README.md:58)"),
     "C3": dict(env="RandomHalfCheetahNoisy-v0", batch=16384, dr="cheetah",
@@ -70,6 +86,8 @@ def apply_dr(env, mode):
     """The DR distribution of a configuration; returns a description for the JSON line."""
     import numpy as np
     nom = np.asarray(env.original_task, dtype=np.float64)
+    if mode == "none":
+        return "no DR (nominal xi)"
     if mode == "readme":
         env.set_dr_distribution("uniform", [0.9, 1.1, 1.9, 2.1, 2.9, 3.1, 3.9, 4.1])
         return "uniform xi [0.9,1.1]x[1.9,2.1]x[2.9,3.1]x[3.9,4.1]"
@@ -135,6 +153,28 @@ def cpu_baseline(env_id, kind, q, v, xi, acts, steps, seed=0, min_seconds=12.0, 
                        % (env_id, n, steps, resets, reps, cores, dt))
 
 
+def cpu_baseline_cartpole(env_id, q, v, xi, acts, min_seconds=3.0):
+    """C1's CPU leg: the fp64 port of RandomCartPoleEnv.step (oracle/cartpole.c, pinned bit-exact to the reference by tests/golden/cartpole_*.json)
+    stepping the GPU leg's own settled states one batched call per env-step -- at batch 1 that is the reference's usage shape, one env on one core
+    (test_random_policy.py:25-32), ctypes call overhead included; finished envs restart from U(-0.05, 0.05)^4 (random_cartpole.py:226-229)."""
+    import numpy as np
+    from oracle_bindings import oracle_cartpole_step
+    n = q.shape[0]
+    rng = np.random.RandomState(0)
+    st = np.stack([q[:, 0], v[:, 0], q[:, 1], v[:, 1]], 1)   # (x, x_dot, theta, theta_dot)
+    steps, dt, resets = 0, 0.0, 0
+    t0 = time.perf_counter()
+    while dt < min_seconds:
+        for k in range(256):
+            st, _, done = oracle_cartpole_step(st, acts[k % len(acts)], xi)
+            if done.any():
+                st[done] = rng.uniform(-0.05, 0.05, (int(done.sum()), 4)); resets += int(done.sum())
+        steps += 256; dt = time.perf_counter() - t0
+    return dict(value=n * steps / dt, unit="env-steps/s", cores=1, kind="port", one_env_one_core=(steps / dt) if n == 1 else None,
+                sample="%s: the GPU leg's %d settled env(s) x %d env-steps through oracle/cartpole.c (one ctypes call per batched step), "
+                       "%d resets, fp64, 1 thread, %.1f s" % (env_id, n, steps, resets, dt))
+
+
 def source_digest():
     """sha256 over the kernel sources: ties a committed PMC traffic figure to the code it was measured on."""
     import hashlib
@@ -170,19 +210,42 @@ def self_launch(n):
     """`bench.py --gpus N` without a launcher: start N ranks as child processes (nothing in this parent has touched the GPU
     or imported torch), hand each its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, relay their output, exit with the worst code."""
     import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rc = 0
-    for p in procs:
-        p.wait(); rc = rc or p.returncode
-    sys.stdout.write(out0); sys.stdout.flush()
+    import tempfile
+    rc = 1
+    for attempt in range(3):   # the rendezvous port is picked by bind(0) and released before rank 0 listens on it: retry if somebody took it
+        s = socket.socket(); s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out0 = tempfile.TemporaryFile()   # rank 0's stdout goes to a file: nothing to drain, so the parent is free to supervise
+        err0 = tempfile.TemporaryFile()
+        procs = []
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err0 if r == 0 else None))
+        # supervise: the first rank that exits non-zero ends the run at once (its siblings would otherwise sit in the rendezvous or in a
+        # collective until torch's 10- to 30-minute timeout, holding the GPUs)
+        rc, live = 0, list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                if p.poll() is not None:
+                    live.remove(p)
+                    rc = rc or p.returncode
+        if rc != 0:
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill(); p.wait()
+        err0.seek(0); err = err0.read().decode(errors="replace")
+        if rc != 0 and attempt < 2 and ("EADDRINUSE" in err or "Address already in use" in err):
+            continue
+        sys.stderr.write(err)
+        out0.seek(0); sys.stdout.write(out0.read().decode()); sys.stdout.flush()
+        break
     sys.exit(rc)
 
 
@@ -211,6 +274,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the launch path on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--cpu-sample-steps", type=int, default=8)
+    ap.add_argument("--pin-shape", action="store_true",
+                    help="strong scaling: every shard runs the launch shape the GLOBAL batch gets on one GPU (sharding.pin_global_shape), so the "
+                         "sharded run reproduces the single-GPU trajectories bit for bit; default: each shard runs the fastest shape for its own size")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -243,13 +309,18 @@ def main():
         env_offset, B = sharding.shard(batch, rank)                 # fixed per-GPU batch
     kind = IDS[env_id][0]
     env = rex.make(env_id, batch=B, device=local_rank, seed=0, env_offset=env_offset, autoreset=not args.replay)
+    if args.pin_shape and args.scaling == "strong":
+        sharding.pin_global_shape(env, batch)
     dr_note = apply_dr(env, cfg.get("dr"))
-    env.set_dr_training(True)
+    env.set_dr_training(cfg.get("dr") != "none")
     env.reset()
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     nact = 16
     amp = float(env.dims.act_high)   # U(-1,1) (hopper/walker/cheetah) or U(-0.4,0.4) (humanoid, humanoid.xml:6)
-    actions = [((torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1) * amp).cuda(local_rank).contiguous() for _ in range(nact)]
+    if kind == "cartpole":           # Discrete(2): action_space.sample() of test_random_policy.py:26
+        actions = [torch.randint(0, 2, (B,), generator=g, dtype=torch.int32).cuda(local_rank).contiguous() for _ in range(nact)]
+    else:
+        actions = [((torch.rand(env.dims.act_dim, B, generator=g) * 2 - 1) * amp).cuda(local_rank).contiguous() for _ in range(nact)]
     if args.replay:
         # the logged transition: the state reached after a few random steps of env 0, replicated; candidates: fresh xi draws
         for k in range(8):
@@ -288,7 +359,7 @@ def main():
         one_step(k)
     sync()
     env.read_timing()                                        # drop the warm-up samples
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.replay and kind != "cartpole"
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.replay
     if want_cpu:                                             # the CPU leg starts from exactly these states
         qs, vs = env.get_state(); xs = env.get_task()
         settled = [z.clone() for z in (qs, vs, xs)]
@@ -334,13 +405,16 @@ def main():
         achieved_wall = bytes_step * B / (wall_ms * 1e-3) / 1e9
         traffic, stale = pmc_traffic(args.config or env_id, B, kernel_of(kind, shape)) if not args.replay else (None, False)
         out = {
-            "metric": METRIC, "value": value, "unit": "env-steps/s",
+            "metric": metric_of(env_id, B, batch if args.scaling == "strong" else B * world, world, args.scaling, args.replay),
+            "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_ms,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s%s%s, batch %d per GPU, %s, U(-%.1f,%.1f) actions, %s"
+            "config": {"workload": "%s%s%s, batch %d per GPU, %s, %s actions, %s"
                                    % (("%s: " % args.config) if args.config else "", env_id,
-                                      " [replay: 1 logged transition x B candidate xi]" if args.replay else "", B, dr_note, amp, amp,
-                                      "one fused rex_replay launch per call" if args.replay else "auto-reset + xi resample"),
+                                      " [replay: 1 logged transition x B candidate xi]" if args.replay else "", B, dr_note,
+                                      "U{0,1}" if kind == "cartpole" else "U(-%.1f,%.1f)" % (amp, amp),
+                                      "one fused rex_replay launch per call" if args.replay else
+                                      ("auto-reset" if cfg.get("dr") == "none" else "auto-reset + xi resample")),
                        "global_batch": total_steps // max(args.steps, 1),
                        "parallelism": "index-sharded envs x%d (%s scaling), no data-path collective; step counter all-reduced "
                                       "asynchronously every %d steps" % (world, args.scaling, args.counter_every)},
@@ -368,9 +442,12 @@ def main():
             import numpy as np
             qs, vs, xs = [z.cpu().double().numpy() for z in settled]
             n_cpu_steps = max(1, min(args.cpu_sample_steps, args.steps))
-            acts = np.stack([actions[k % nact].t().cpu().double().numpy() for k in range(n_cpu_steps)])
-            out["cpu_baseline"] = cpu_baseline(env_id, kind, qs, vs, xs, acts, n_cpu_steps,
-                                               max_envs=4096 if kind == "humanoid" else None)
+            if kind == "cartpole":
+                out["cpu_baseline"] = cpu_baseline_cartpole(env_id, qs, vs, xs, [a.cpu().numpy() for a in actions])
+            else:
+                acts = np.stack([actions[k % nact].t().cpu().double().numpy() for k in range(n_cpu_steps)])
+                out["cpu_baseline"] = cpu_baseline(env_id, kind, qs, vs, xs, acts, n_cpu_steps,
+                                                   max_envs=4096 if kind == "humanoid" else None)
         print(json.dumps(out), flush=True)
     env.close()
     sharding.shutdown()

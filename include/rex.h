@@ -22,7 +22,12 @@
  *   - internal state is SoA [field][env]; I/O buffers are SoA too: obs is [obs_dim][batch],
  *     action is [act_dim][batch], xi is [task_dim][batch] (a torch [batch, dim] view is the
  *     zero-copy transpose).  reward is float[batch], done / truncated are uint8[batch].
- *   - a handle is bound to one device; calls on one handle are not re-entrant.
+ *   - a handle is bound to one device; calls on one handle are not re-entrant.  Every entry point that enqueues work, copies or
+ *     synchronises makes the handle's device the calling thread's current device first, so one thread may drive one handle per GPU.
+ *   - environment: REX_LANES / REX_PAIR / REX_ROLLED / REX_HUM_PAIR / REX_HUM_FUSED_RESET / REX_FUSED_DERIVE (launch shape) and
+ *     REX_FAST / REX_LS_MAX / REX_LS_FREE / REX_WARM / REX_CORR (solver schedule) are A/B and test knobs: rex_create honours them only
+ *     with REX_ALLOW_TUNING=1 and otherwise REFUSES to create a handle while one is set (REX_ERR_STATE).  Nothing else is read from
+ *     the environment.
  */
 #ifndef REX_H_
 #define REX_H_
@@ -127,7 +132,8 @@ int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, ui
  * random_walker2d.py:106-113), so a derive launch into replay scratch precedes the step launch.  Humanoid: the forward
  * launch of set_state (data.xipos for mass_center(), jinja_mujoco_env.py:154) precedes it.  Unmodeled ids: one scatter
  * launch places the reduced task over the handle's frozen rows in a scratch copy of the full xi block.  The scratch is
- * allocated by the first such call.  RandomCartPole: REX_ERR_UNSUPPORTED (the reference has no such helpers for it). */
+ * allocated by the first such call (which therefore synchronises the device) and belongs to the handle: issue the replays of one
+ * handle on one stream at a time.  RandomCartPole: REX_ERR_UNSUPPORTED (the reference has no such helpers for it). */
 int rex_replay(rex_t* h, const float* qpos, const float* qvel, const float* xi, const float* action,
                float* obs_out, float* reward_out, uint8_t* done_out, void* stream);
 
@@ -174,12 +180,18 @@ int64_t rex_step_count(const rex_t* h);
  * [2] constraint solves that hit the iteration cap. Copies 4 int64 to `out` [host]; synchronises. */
 int rex_get_counters(rex_t* h, int64_t* out);
 
-/* the launch shape rex_create picked for this handle from its batch and the GPU's SIMD count (the REX_LANES / REX_PAIR /
- * REX_ROLLED / REX_HUM_PAIR knobs override): out[0] lanes per workgroup of the one-lane-per-env launches, out[1] 1 = the planar step runs
+/* the launch shape rex_create picked for this handle from its batch and the GPU's SIMD count (rex_set_launch_shape and,
+ * under REX_ALLOW_TUNING=1, the REX_LANES / REX_PAIR / REX_ROLLED / REX_HUM_PAIR knobs override): out[0] lanes per workgroup of the one-lane-per-env launches, out[1] 1 = the planar step runs
  * two lanes per env, out[2] 1 = hopper step on the 256-register kernel with the rolled general solver (two waves per SIMD), out[3] 1 = the
  * humanoid step runs two lanes per env.  No reference counterpart (the reference steps one MjSim on one core); bench.py names the launched
  * kernel from it.  Writes 4 int32 to `out` [host]. */
 int rex_get_launch_shape(const rex_t* h, int32_t* out);
+/* Pins the launch shape of a handle (same four int32 as rex_get_launch_shape, [host]; -1 keeps a field): every shape runs the same solver to
+ * the same minimiser, but which solver instantiation a wave enters depends on the shape, so two runs agree bit for bit only under the same
+ * shape.  sharding.shard_strong pins every shard to the shape the GLOBAL batch would get on one GPU, which makes an index-sharded run reproduce the
+ * single-GPU trajectories exactly.  Pure host bookkeeping (the shape is read at launch time); REX_ERR_ARG for a shape the env kind has no kernel
+ * for.  No reference counterpart. */
+int rex_set_launch_shape(rex_t* h, const int32_t* shape);
 
 /* duration in ms of the sampled rex_step kernel launches since the last enable / read (at most the last 8192), measured
  * with HIP events on the launch stream; returns the number of samples written.  The two event packets of a bracketed launch

@@ -4,7 +4,7 @@
   -> profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
      profiles/<tag>_pmc_summary.json   per-launch means of every counter, per kernel
      profiles/hbm_traffic.json[key]    HBM bytes per launch of the step kernel + digest of the sources profiled
-     profiles/r03_configs.json[key]    the bench line next to the rocprof average of its kernel"""
+     profiles/<round>_configs.json[key]  the bench line next to the rocprof average of its kernel (<round> = the tag's prefix, "r04_c2" -> r04)"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,7 +60,7 @@ if traffic is not None:
     rec[key] = {"kernel": kname, "batch": int(line["config"]["global_batch"]) // max(int(line["n_gpus"]), 1), "bytes_per_launch": traffic, "source_digest": bench.source_digest(),
                 "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag}
     json.dump(rec, open(tp, "w"), indent=1)
-cp = os.path.join(ROOT, "profiles", "r03_configs.json")
+cp = os.path.join(ROOT, "profiles", tag.split("_")[0] + "_configs.json")
 try:
     cfgs = json.load(open(cp))
 except Exception:

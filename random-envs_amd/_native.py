@@ -16,7 +16,7 @@ SYMBOLS = [
     "rex_get_task", "rex_set_task", "rex_set_random_task", "rex_get_obs", "rex_step_count",
     "rex_get_counters", "rex_enable_timing", "rex_read_timing", "rex_last_error", "rex_version",
     "rex_get_counters_state", "rex_set_counters_state", "rex_sample_task", "rex_set_info_buffer", "rex_export_lane", "rex_get_aux", "rex_set_aux", "rex_replay",
-    "rex_get_launch_shape",
+    "rex_get_launch_shape", "rex_set_launch_shape",
 ]
 
 ENV_KINDS = {"cartpole": 0, "hopper": 1, "halfcheetah": 2, "walker2d": 3, "humanoid": 4}
@@ -70,6 +70,7 @@ def lib():
     L.rex_step_count.restype = i64
     L.rex_get_counters.argtypes = [vp, ctypes.POINTER(i64)]
     L.rex_get_launch_shape.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    L.rex_set_launch_shape.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.rex_enable_timing.argtypes = [vp, i32]
     L.rex_read_timing.argtypes = [vp, fp, i32]
     L.rex_get_counters_state.argtypes = [vp, vp, vp, vp, vp]

@@ -837,6 +837,20 @@ REX_HD void pin_all(T (&a)[NP]) { if constexpr (Q < NP) { REX_PIN4(a[Q], a[Q + 1
 #define REX_PGS_CHECK 10
 #endif
 constexpr int PGS_CHECK = REX_PGS_CHECK;   // the device sweeps evaluate the stopping criterion every PGS_CHECK-th sweep (pgs_sweeps_sq)
+
+// How often a sweep evaluates the stopping criterion: every PGS_CHECK-th sweep in the fp32 device code (pgs_sweeps_sq has the argument), every
+// sweep ([3P] mj_solPGS) in the host instantiations -- unless the harness is built with -DREX_PGS_CHECK_HOST, which gives the fp32 host code the
+// DEVICE's schedule so a host test exercises exactly the sweep counts the GPU runs (tests/test_humanoid_host.py).  REX_PGS_CHECK itself is a
+// compile-time define: it reaches the product only through the hipcc flags, which __graft_entry__ hashes into librex_hip.so.digest.
+template <class T> constexpr int pgs_check_period() {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(REX_PGS_CHECK_HOST)
+  return sizeof(T) == 4 ? PGS_CHECK : 1;
+#else
+  return 1;
+#endif
+}
+// is the criterion evaluated after sweep `it` (0-based) of at most `iters`?  (groups of K - 1 unchecked sweeps + one checked, the last sweep always checked)
+template <class T> REX_HD bool pgs_checked(int it, int iters) { constexpr int K = pgs_check_period<T>(); return K == 1 || (it + 1) % K == 0 || it + 1 == iters; }
 template <int NC, int I, class T>
 REX_HD void pgs_load_row(const T* col, T (&a)[(NC + 3) / 4 * 4 + 2]) {   // row I of the packed A, then b_I and 1 / A_II
   constexpr int NP = (NC + 3) / 4 * 4;
@@ -896,11 +910,7 @@ REX_HD int pgs_sweeps(const Model<T>& m, const T* col, int n, T (&f)[DUAL_NMAX])
     });
   };
   // the stopping criterion in every K-th sweep only on the device (pgs_sweeps_sq has the argument); every sweep on the host
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int K = sizeof(T) == 4 ? PGS_CHECK : 1;
-#else
-  constexpr int K = 1;
-#endif
+  constexpr int K = pgs_check_period<T>();
   while (it < m.iterations) {
     int nun = m.iterations - 1 - it; nun = nun < K - 1 ? nun : K - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -997,7 +1007,7 @@ REX_HD int pgs_sweeps_sq(const Model<T>& m, const T* col, T (&f)[DUAL_NMAX]) {
         f[i] = nf;
         improvement -= df * (T(0.5) * df * col[i * NP + i] + res);
       }
-      if (improvement * scale < m.tolerance) { it++; break; }
+      if (pgs_checked<T>(it, m.iterations) && improvement * scale < m.tolerance) { it++; break; }
     }
     return it;
   }

@@ -802,7 +802,7 @@ REX_HD int pgs_sweeps_seg(const P& p, const Model<T>& m, const T* col, T (&f)[DU
         f[i] = nf;
         improvement -= df * (T(0.5) * df * a + res);
       }
-      if (improvement * scale < m.tolerance) { it++; break; }
+      if (pgs_checked<T>(it, m.iterations) && improvement * scale < m.tolerance) { it++; break; }
     }
     return it;
   }

@@ -98,6 +98,28 @@ static int set_err(int code, const char* fmt, ...) {
 extern "C" const char* rex_last_error(void) { return g_err; }
 extern "C" const char* rex_version(void) { return "rex-hip 0.1 (gfx950)"; }
 
+// First statement of every entry point that enqueues work, copies or synchronises on behalf of a handle: the handle's device becomes the
+// calling thread's current device (one process may drive one handle per GPU: SURVEY.md 8(b) "Threading").  tests/test_abi.py parses this file
+// and fails on an exported function that takes a handle and launches / copies without it.
+#define REX_ENTER(h, fn)                                                    \
+  do { if (!(h)) return set_err(REX_ERR_ARG, fn ": null handle"); HIP_TRY(hipSetDevice((h)->device)); } while (0)
+
+// Environment knobs.  They select among the product's own launch shapes and solver schedules (every choice converges to the same
+// minimiser) and exist for A/B measurements and for the parity tests that hold every shape to the oracle.  A stray variable
+// must not change what a production process runs, so a knob is honoured only when REX_ALLOW_TUNING=1 is set beside it and rex_create
+// REFUSES (REX_ERR_STATE) a handle when a knob is set without it.  Knobs that change the physics (no floor contacts, a PGS sweep cap)
+// exist only in -DREX_TUNING builds, which build() never produces.
+static const char* const kKnobs[] = {"REX_LANES", "REX_PAIR", "REX_ROLLED", "REX_HUM_PAIR", "REX_HUM_FUSED_RESET", "REX_FUSED_DERIVE",
+                                     "REX_FAST", "REX_LS_MAX", "REX_LS_FREE", "REX_WARM", "REX_CORR",
+                                     "REX_DIAG_NOCONTACT", "REX_HUM_ITERS"};
+static bool tuning_allowed() { const char* e = getenv("REX_ALLOW_TUNING"); return e && atoi(e) == 1; }
+static const char* stray_knob() {   // a knob set without REX_ALLOW_TUNING=1, or null
+  if (tuning_allowed()) return nullptr;
+  for (const char* k : kKnobs) if (getenv(k)) return k;
+  return nullptr;
+}
+static const char* knob(const char* name) { return tuning_allowed() ? getenv(name) : nullptr; }
+
 // ------------------------------------------------------------------------------------------
 // DR distribution block (device-visible copy of RandomEnv's min/max/mean/stdev/cov state,
 // random_env.py:102-127)
@@ -938,7 +960,7 @@ static int simds_of(int device_id) {
   return 4 * cus;
 }
 static int lanes_for(long long B, int simds) {
-  const char* e = getenv("REX_LANES");
+  const char* e = knob("REX_LANES");
   if (e && atoi(e) > 0) return atoi(e);
   return B > 32ll * simds ? 64 : 32;
 }
@@ -959,23 +981,28 @@ static int launch_walker_derive(rex_env* h, const unsigned char* mask, int bit, 
   return REX_OK;
 }
 
-extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_id, uint64_t seed, int64_t env_offset,
-                          rex_t** out) {
-  if (!out) return set_err(REX_ERR_ARG, "rex_create: null out");
-  if (batch <= 0) return set_err(REX_ERR_ARG, "rex_create: batch must be > 0 (got %lld)", (long long)batch);
-  rex_dims dims, full;
-  if (fill_dims(env_kind, variant, &dims) || fill_dims(env_kind, 0, &full))
-    return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
-#ifdef REX_ONLY_KIND
-  if (env_kind != REX_ONLY_KIND) return set_err(REX_ERR_UNSUPPORTED, "this tuning build holds env kind %d only", (int)REX_ONLY_KIND);
+// the humanoid's compiled model: built once per process (magic static: thread-safe), shared by every handle
+#if REX_EN_HUMANOID
+struct HumModels { hum::Model<double> md; hum::Model<float> mf; const char* err = nullptr; };
+static const HumModels& hum_models() {
+  static const HumModels* m = [] {
+    HumModels* p = new HumModels();
+    hum::build_model(p->md);
+    if (!hum::check_topology(p->md)) p->err = "humanoid: compile-time dof tree differs from the model tables";
+    else if (!hum::pr::check_pair_model(p->md)) p->err = "humanoid: a side body carries an orientation offset (humanoid_pair.hpp assumes none)";
+    else hum::convert_model(p->md, p->mf);
+    return p;
+  }();
+  return *m;
+}
 #endif
-  HIP_TRY(hipSetDevice(device_id));
-  rex_env* h = new (std::nothrow) rex_env();
-  if (!h) return set_err(REX_ERR_ARG, "out of host memory");
-  h->kind = env_kind; h->variant = variant; h->device = device_id; h->B = batch; h->env_offset = env_offset; h->seed = seed;
+
+// everything of rex_create that can fail after the handle exists: on any error the caller destroys the handle, which frees
+// whatever was allocated up to that point (every device pointer of a fresh rex_env is null)
+static int create_body(rex_env* h, int env_kind, int variant, int64_t batch, int device_id, const rex_dims& dims, const rex_dims& full) {
   const int simds = simds_of(device_id);
   h->lanes = lanes_for(batch, simds);
-  if (h->lanes < 8 || h->lanes > 64 || (h->lanes & (h->lanes - 1))) { int l = h->lanes; delete h; return set_err(REX_ERR_ARG, "REX_LANES must be 8, 16, 32 or 64 (got %d)", l); }
+  if (h->lanes < 8 || h->lanes > 64 || (h->lanes & (h->lanes - 1))) return set_err(REX_ERR_ARG, "REX_LANES must be 8, 16, 32 or 64 (got %d)", h->lanes);
   h->dims = dims;
   h->flags.endless = 0; h->flags.noisy = 0; h->flags.time_limit = 1; h->flags.max_steps = dims.max_episode_steps;
   h->flags.noise_std = 0.0f; h->flags.info = nullptr; h->flags.readonly = 0;
@@ -984,7 +1011,7 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
   variant_map(env_kind, variant, full.task_dim, h->dr.map);
   const size_t B = (size_t)batch;
   DevState& d = h->dev;
-  d.B = batch; d.env_offset = env_offset; d.seed = seed;
+  d.B = batch; d.env_offset = h->env_offset; d.seed = h->seed;
   HIP_TRY(hipMalloc(&d.qpos, sizeof(float) * dims.nq * B));
   HIP_TRY(hipMalloc(&d.qvel, sizeof(float) * dims.nv * B));
   HIP_TRY(hipMalloc(&d.xi, sizeof(float) * full.task_dim * B));
@@ -1023,15 +1050,13 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
       noise_var = Walker2dSpec::DEFAULT_NOISE_VAR; break; }
 #if REX_EN_HUMANOID
     case REX_HUMANOID: {
-      static hum::Model<double> md; static hum::Model<float> mf; static bool built = false;
-      if (!built) {
-        hum::build_model(md);
-        if (!hum::check_topology(md)) return set_err(REX_ERR_ARG, "humanoid: compile-time dof tree differs from the model tables");
-        if (!hum::pr::check_pair_model(md)) return set_err(REX_ERR_ARG, "humanoid: a side body carries an orientation offset (humanoid_pair.hpp assumes none)");
-        hum::convert_model(md, mf); built = true;
-      }
-      { hum::Model<float> up = mf;   // diagnostics: REX_HUM_ITERS caps the PGS sweeps (timing experiments only)
-        if (getenv("REX_HUM_ITERS")) up.iterations = atoi(getenv("REX_HUM_ITERS"));
+      const HumModels& hm = hum_models();
+      if (hm.err) return set_err(REX_ERR_ARG, "%s", hm.err);
+      const hum::Model<double>& md = hm.md;
+      { hum::Model<float> up = hm.mf;
+#if defined(REX_TUNING)   // timing experiments only (changes the physics): a cap on the PGS sweeps
+        if (knob("REX_HUM_ITERS")) up.iterations = atoi(knob("REX_HUM_ITERS"));
+#endif
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hum), &up, sizeof up)); }
       {   // 64-lane blocks need more than the default 64 KB of dynamic LDS
         const int lds = (int)(sizeof(float) * hum::DUAL_WORDS * 64);
@@ -1052,23 +1077,26 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
 #endif
   }
   h->flags.noise_std = sqrtf(noise_var);
-  if (getenv("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;   // timing diagnostics only: no floor contacts ever
-  if (getenv("REX_LS_MAX")) h->sp.ls_max = atoi(getenv("REX_LS_MAX"));   // tuning knobs
-  if (getenv("REX_WARM")) h->sp.warm = atoi(getenv("REX_WARM"));
-  if (getenv("REX_LS_FREE")) h->sp.ls_free = atoi(getenv("REX_LS_FREE"));
-  if (getenv("REX_CORR")) h->sp.corr = atoi(getenv("REX_CORR"));
-  if (getenv("REX_FAST")) h->sp.fast = atoi(getenv("REX_FAST"));
-  // launch shape by batch (lanes_for above has the measurements)
+#if defined(REX_TUNING)   // timing diagnostics only (changes the physics): no floor contacts ever
+  if (knob("REX_DIAG_NOCONTACT")) h->sp.con_margin = -1e9f;
+#endif
+  // solver schedule (every schedule reaches the same minimiser: tests/test_gpu_planar.py runs them all against the oracle)
+  if (knob("REX_LS_MAX")) h->sp.ls_max = atoi(knob("REX_LS_MAX"));
+  if (knob("REX_WARM")) h->sp.warm = atoi(knob("REX_WARM"));
+  if (knob("REX_LS_FREE")) h->sp.ls_free = atoi(knob("REX_LS_FREE"));
+  if (knob("REX_CORR")) h->sp.corr = atoi(knob("REX_CORR"));
+  if (knob("REX_FAST")) h->sp.fast = atoi(knob("REX_FAST"));
+  // launch shape by batch (lanes_for above has the measurements); rex_set_launch_shape overrides it per handle
   h->pair = batch <= 32ll * simds ? 1 : 0;
   h->rolled = (env_kind == REX_HOPPER && batch > 64ll * simds) ? 1 : 0;
-  if (getenv("REX_PAIR")) h->pair = atoi(getenv("REX_PAIR")) ? 1 : 0;
-  if (getenv("REX_ROLLED")) h->rolled = (env_kind == REX_HOPPER && atoi(getenv("REX_ROLLED"))) ? 1 : 0;
-  if (getenv("REX_HUM_PAIR")) h->hum_pair = atoi(getenv("REX_HUM_PAIR")) ? 1 : 0;
-  if (getenv("REX_HUM_FUSED_RESET")) h->hum_fused_reset = atoi(getenv("REX_HUM_FUSED_RESET")) ? 1 : 0;
+  if (knob("REX_PAIR")) h->pair = atoi(knob("REX_PAIR")) ? 1 : 0;
+  if (knob("REX_ROLLED")) h->rolled = (env_kind == REX_HOPPER && atoi(knob("REX_ROLLED"))) ? 1 : 0;
+  if (knob("REX_HUM_PAIR")) h->hum_pair = atoi(knob("REX_HUM_PAIR")) ? 1 : 0;
+  if (knob("REX_HUM_FUSED_RESET")) h->hum_fused_reset = atoi(knob("REX_HUM_FUSED_RESET")) ? 1 : 0;
   // walker2d: derive fused into the step kernel (inlined in the pair kernel, a call in the one-lane one) while the two small launches behind a
   // step are a visible share of it (32 768 envs: + 10 % env-steps/s, 65 536: + 9 %, 131 072: + 4.5 %, 2^20: - 0.5 %)
   h->fused_derive = batch < 524288 ? 1 : 0;
-  if (getenv("REX_FUSED_DERIVE")) h->fused_derive = atoi(getenv("REX_FUSED_DERIVE")) ? 1 : 0;
+  if (knob("REX_FUSED_DERIVE")) h->fused_derive = atoi(knob("REX_FUSED_DERIVE")) ? 1 : 0;
   if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
   if (h->pair) h->rolled = 0;     // the two-waves-per-SIMD kernel is a one-lane-per-env one
   // xi <- nominal task, state <- qpos0
@@ -1095,6 +1123,38 @@ extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_i
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipDeviceSynchronize());
+  return REX_OK;
+}
+
+extern "C" int rex_destroy(rex_t* h);
+extern "C" int rex_create(int env_kind, int variant, int64_t batch, int device_id, uint64_t seed, int64_t env_offset,
+                          rex_t** out) {
+  if (!out) return set_err(REX_ERR_ARG, "rex_create: null out");
+  *out = nullptr;
+  if (batch <= 0) return set_err(REX_ERR_ARG, "rex_create: batch must be > 0 (got %lld)", (long long)batch);
+  rex_dims dims, full;
+  if (fill_dims(env_kind, variant, &dims) || fill_dims(env_kind, 0, &full))
+    return set_err(REX_ERR_ARG, "unknown env kind %d / variant %d", env_kind, variant);
+#ifdef REX_ONLY_KIND
+  if (env_kind != REX_ONLY_KIND) return set_err(REX_ERR_UNSUPPORTED, "this tuning build holds env kind %d only", (int)REX_ONLY_KIND);
+#endif
+  if (const char* k = stray_knob())
+    return set_err(REX_ERR_STATE, "rex_create: %s is set but REX_ALLOW_TUNING=1 is not: tuning knobs are refused in production (unset it, or set REX_ALLOW_TUNING=1)", k);
+#if !defined(REX_TUNING)
+  if (getenv("REX_DIAG_NOCONTACT") || getenv("REX_HUM_ITERS"))
+    return set_err(REX_ERR_UNSUPPORTED, "rex_create: REX_DIAG_NOCONTACT / REX_HUM_ITERS change the physics and exist in -DREX_TUNING builds only");
+#endif
+  HIP_TRY(hipSetDevice(device_id));
+  rex_env* h = new (std::nothrow) rex_env();
+  if (!h) return set_err(REX_ERR_ARG, "out of host memory");
+  h->kind = env_kind; h->variant = variant; h->device = device_id; h->B = batch; h->env_offset = env_offset; h->seed = seed;
+  const int rc = create_body(h, env_kind, variant, batch, device_id, dims, full);
+  if (rc != REX_OK) {   // one cleanup for every failure path: the handle and whatever it had allocated (the message of the failure is kept)
+    char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep);
+    rex_destroy(h);
+    memcpy(g_err, keep, sizeof keep);
+    return rc;
+  }
   *out = h;
   return REX_OK;
 }
@@ -1117,7 +1177,7 @@ extern "C" int rex_destroy(rex_t* h) {
 }
 
 extern "C" int rex_set_dr(rex_t* h, int dr_type, const float* params, int n_params, const float* lower_bounds) {
-  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  REX_ENTER(h, "rex_set_dr");
   const int d = h->dims.task_dim;
   DRParams& dr = h->dr;
   switch (dr_type) {
@@ -1130,7 +1190,7 @@ extern "C" int rex_set_dr(rex_t* h, int dr_type, const float* params, int n_para
       for (int i = 0; i < d; i++) dr.a[i] = params[i];
       { static thread_local float hc[MAX_XI * MAX_XI]; memset(hc, 0, sizeof hc);
         for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) hc[i * MAX_XI + j] = params[d + i * d + j];
-        HIP_TRY(hipSetDevice(h->device)); HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h->d_chol, hc, sizeof hc, hipMemcpyHostToDevice)); }
       for (int i = 0; i < d; i++) { dr.lo[i] = params[d + d * d + i]; dr.hi[i] = params[2 * d + d * d + i]; }
       break;
@@ -1183,15 +1243,13 @@ static int do_reset(rex_t* h, const unsigned char* mask, int bit, int resample, 
 }
 
 extern "C" int rex_reset(rex_t* h, const uint8_t* mask, float* obs_out, void* stream) {
-  if (!h) return set_err(REX_ERR_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  REX_ENTER(h, "rex_reset");
   // CartPole.reset() never resamples (random_cartpole.py:226-229); the MuJoCo envs do when dr_training
   int resample = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
   return do_reset(h, mask, 1, resample, 1, obs_out, (hipStream_t)stream);
 }
 extern "C" int rex_set_random_task(rex_t* h, const uint8_t* mask, void* stream) {
-  if (!h) return set_err(REX_ERR_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  REX_ENTER(h, "rex_set_random_task");
   return do_reset(h, mask, 1, 1, 0, nullptr, (hipStream_t)stream);
 }
 
@@ -1232,10 +1290,9 @@ static void launch_humanoid_step(rex_env* h, const DevState& dev, const StepFlag
 
 extern "C" int rex_step(rex_t* h, const void* action, float* obs_out, float* reward_out, uint8_t* done_out,
                         uint8_t* truncated_out, float* terminal_obs_out, void* stream) {
-  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  REX_ENTER(h, "rex_step");
   if (!action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_step: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipSetDevice(h->device));
   const dim3 g(grid_for(h)), b(lanes_of(h));
   const int resample_on_reset = (h->dr_training && h->kind != REX_CARTPOLE) ? 1 : 0;
   // planar envs reset finished lanes inside the step kernel (walker2d under DR re-derives the lane's geometry there as well)
@@ -1294,21 +1351,41 @@ __global__ void replay_xi_kernel(float* __restrict__ dst, const float* __restric
   for (int k = 0; k < task_dim; k++) dst[(size_t)map[k] * B + i] = task[(size_t)k * B + i];
 }
 
+// rex_replay's scratch, complete or absent: the first replay of a handle allocates what its kind / id needs (the allocation
+// synchronises the device; later calls only enqueue).  A partial failure frees what it got, so no later call can launch with a
+// half-built set.  The scratch is per HANDLE: replays of one handle must be issued on one stream at a time (rex.h).
+static int ensure_replay_scratch(rex_env* h) {
+  const size_t B = (size_t)h->B;
+  const bool need_xi = h->variant != 0, need_rows = h->kind == REX_WALKER2D || h->kind == REX_HUMANOID;
+  const bool have_xi = h->rp_xi && h->d_map, have_rows = h->rp_rows != nullptr;
+  if ((!need_xi || have_xi) && (!need_rows || have_rows)) return REX_OK;
+  auto drop = [&] { if (h->rp_xi) hipFree(h->rp_xi); if (h->d_map) hipFree(h->d_map); if (h->rp_rows) hipFree(h->rp_rows);
+                    h->rp_xi = nullptr; h->d_map = nullptr; h->rp_rows = nullptr; };
+  hipError_t e = hipSuccess;
+  if (need_xi && !have_xi) {
+    if (e == hipSuccess && !h->rp_xi) e = hipMalloc(&h->rp_xi, sizeof(float) * h->full_dim * B);
+    if (e == hipSuccess && !h->d_map) e = hipMalloc(&h->d_map, sizeof(int) * MAX_XI);
+    if (e == hipSuccess) e = hipMemcpy(h->d_map, h->dr.map, sizeof(int) * MAX_XI, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && need_rows && !have_rows) {
+    const size_t rows = h->kind == REX_WALKER2D ? (size_t)kWalkerCompact : (size_t)hum::NBODY;
+    e = hipMalloc(&h->rp_rows, sizeof(float) * rows * B);
+  }
+  if (e != hipSuccess) { drop(); return set_err(REX_ERR_HIP, "rex_replay: scratch allocation failed: %s", hipGetErrorString(e)); }
+  return REX_OK;
+}
+
 extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const float* xi, const float* action,
                           float* obs_out, float* reward_out, uint8_t* done_out, void* stream) {
-  if (!h || !qpos || !qvel || !xi || !action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_replay: null argument");
+  REX_ENTER(h, "rex_replay");
+  if (!qpos || !qvel || !xi || !action || !obs_out || !reward_out || !done_out) return set_err(REX_ERR_ARG, "rex_replay: null argument");
   if (h->kind == REX_CARTPOLE) return set_err(REX_ERR_UNSUPPORTED, "rex_replay: RandomCartPoleEnv has no get_full_mjstate / set_sim_state (random_cartpole.py)");
-  HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const size_t B = (size_t)h->B;
   DevState dev = h->dev;                    // the handle's device view with the state rows replaced by the caller's buffers
   dev.qpos = const_cast<float*>(qpos); dev.qvel = const_cast<float*>(qvel); dev.xi = const_cast<float*>(xi);
+  { int rc = ensure_replay_scratch(h); if (rc) return rc; }
   if (h->variant) {                          // reduced task -> scratch copy of the full xi block
-    if (!h->rp_xi) {
-      HIP_TRY(hipMalloc(&h->rp_xi, sizeof(float) * h->full_dim * B));
-      HIP_TRY(hipMalloc(&h->d_map, sizeof(int) * MAX_XI));
-      HIP_TRY(hipMemcpy(h->d_map, h->dr.map, sizeof(int) * MAX_XI, hipMemcpyHostToDevice));
-    }
     hipLaunchKernelGGL(replay_xi_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, h->rp_xi, h->dev.xi, xi, h->d_map,
                        h->full_dim, h->dims.task_dim, (long long)B);
     HIP_TRY(hipGetLastError());
@@ -1316,7 +1393,6 @@ extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const 
   }
 #if REX_EN_WALKER2D
   if (h->kind == REX_WALKER2D) {             // geometry of the caller's xi lengths (what set_task's build_model does)
-    if (!h->rp_rows) HIP_TRY(hipMalloc(&h->rp_rows, sizeof(float) * kWalkerCompact * B));
     dev.geom = h->rp_rows;
     hipLaunchKernelGGL(walker_derive_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, st, dev, (const unsigned char*)nullptr, 0, h->variant ? 1 : 0, 0);
     HIP_TRY(hipGetLastError());
@@ -1339,9 +1415,9 @@ extern "C" int rex_replay(rex_t* h, const float* qpos, const float* qvel, const 
 #if REX_EN_HUMANOID
     case REX_HUMANOID:   // set_state's sim.forward() (jinja_mujoco_env.py:154) leaves data.xipos for mass_center(): a forward launch into
                          // replay scratch, then the step launch
-      if (!h->rp_rows) HIP_TRY(hipMalloc(&h->rp_rows, sizeof(float) * hum::NBODY * B));
       dev.aux = h->rp_rows;
       hipLaunchKernelGGL(humanoid_forward_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), hum_lds_bytes(h), st, dev, (float*)nullptr);
+      HIP_TRY(hipGetLastError());
       launch_humanoid_step(h, dev, flags, action, obs_out, reward_out, done_out, nullptr, nullptr, st);
       break;
 #endif
@@ -1357,12 +1433,14 @@ static int copy_rows(float* dst, const float* src, int rows, long long B, hipStr
   return REX_OK;
 }
 extern "C" int rex_get_state(rex_t* h, float* qpos, float* qvel, void* stream) {
-  if (!h || !qpos || !qvel) return set_err(REX_ERR_ARG, "rex_get_state: null argument");
+  REX_ENTER(h, "rex_get_state");
+  if (!qpos || !qvel) return set_err(REX_ERR_ARG, "rex_get_state: null argument");
   int rc = copy_rows(qpos, h->dev.qpos, h->dims.nq, h->B, (hipStream_t)stream); if (rc) return rc;
   return copy_rows(qvel, h->dev.qvel, h->dims.nv, h->B, (hipStream_t)stream);
 }
 extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, void* stream) {
-  if (!h || !qpos || !qvel) return set_err(REX_ERR_ARG, "rex_set_state: null argument");
+  REX_ENTER(h, "rex_set_state");
+  if (!qpos || !qvel) return set_err(REX_ERR_ARG, "rex_set_state: null argument");
   int rc = copy_rows(h->dev.qpos, qpos, h->dims.nq, h->B, (hipStream_t)stream); if (rc) return rc;
   rc = copy_rows(h->dev.qvel, qvel, h->dims.nv, h->B, (hipStream_t)stream); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(h->dev.done, 0, (size_t)h->B, (hipStream_t)stream));   // steps_beyond_done = None
@@ -1375,14 +1453,16 @@ extern "C" int rex_set_state(rex_t* h, const float* qpos, const float* qvel, voi
   return REX_OK;
 }
 extern "C" int rex_get_task(rex_t* h, float* xi, void* stream) {
-  if (!h || !xi) return set_err(REX_ERR_ARG, "rex_get_task: null argument");
+  REX_ENTER(h, "rex_get_task");
+  if (!xi) return set_err(REX_ERR_ARG, "rex_get_task: null argument");
   for (int k = 0; k < h->dims.task_dim; k++) {   // task row k = row map[k] of the full xi block
     int rc = copy_rows(xi + (size_t)k * h->B, h->dev.xi + (size_t)h->dr.map[k] * h->B, 1, h->B, (hipStream_t)stream); if (rc) return rc;
   }
   return REX_OK;
 }
 extern "C" int rex_set_task(rex_t* h, const float* xi, void* stream) {
-  if (!h || !xi) return set_err(REX_ERR_ARG, "rex_set_task: null argument");
+  REX_ENTER(h, "rex_set_task");
+  if (!xi) return set_err(REX_ERR_ARG, "rex_set_task: null argument");
   int rc = REX_OK;
   if (!h->variant) rc = copy_rows(h->dev.xi, xi, h->dims.task_dim, h->B, (hipStream_t)stream);   // identity map: one copy
   else for (int k = 0; k < h->dims.task_dim; k++) {
@@ -1393,7 +1473,8 @@ extern "C" int rex_set_task(rex_t* h, const float* xi, void* stream) {
   return REX_OK;
 }
 extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
-  if (!h || !obs_out) return set_err(REX_ERR_ARG, "rex_get_obs: null argument");
+  REX_ENTER(h, "rex_get_obs");
+  if (!obs_out) return set_err(REX_ERR_ARG, "rex_get_obs: null argument");
   const dim3 g(grid_for(h)), b(lanes_of(h)); hipStream_t st = (hipStream_t)stream;
   switch (h->kind) {
 #if REX_EN_CARTPOLE
@@ -1418,8 +1499,8 @@ extern "C" int rex_get_obs(rex_t* h, float* obs_out, void* stream) {
 
 extern "C" int64_t rex_step_count(const rex_t* h) { return h ? h->step_count : 0; }
 extern "C" int rex_get_counters(rex_t* h, int64_t* out) {
-  if (!h || !out) return set_err(REX_ERR_ARG, "rex_get_counters: null argument");
-  HIP_TRY(hipSetDevice(h->device));
+  REX_ENTER(h, "rex_get_counters");
+  if (!out) return set_err(REX_ERR_ARG, "rex_get_counters: null argument");
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, h->dev.counters, sizeof(int64_t) * 4, hipMemcpyDeviceToHost));
   return REX_OK;
@@ -1431,10 +1512,24 @@ extern "C" int rex_get_launch_shape(const rex_t* h, int32_t* out) {
   out[3] = (h->kind == REX_HUMANOID && h->hum_pair) ? 1 : 0;
   return REX_OK;
 }
+extern "C" int rex_set_launch_shape(rex_t* h, const int32_t* shape) {
+  if (!h || !shape) return set_err(REX_ERR_ARG, "rex_set_launch_shape: null argument");
+  const bool planar = h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || h->kind == REX_WALKER2D;
+  int lanes = shape[0] < 0 ? h->lanes : shape[0];
+  int pair = shape[1] < 0 ? h->pair : (shape[1] ? 1 : 0), rolled = shape[2] < 0 ? h->rolled : (shape[2] ? 1 : 0);
+  int hum_pair = shape[3] < 0 ? h->hum_pair : (shape[3] ? 1 : 0);
+  if (lanes < 8 || lanes > 64 || (lanes & (lanes - 1))) return set_err(REX_ERR_ARG, "rex_set_launch_shape: lanes must be 8, 16, 32 or 64 (got %d)", lanes);
+  if (shape[1] > 0 && !planar) return set_err(REX_ERR_ARG, "rex_set_launch_shape: two lanes per env (pair) is a shape of the planar chains");
+  if (shape[2] > 0 && h->kind != REX_HOPPER) return set_err(REX_ERR_ARG, "rex_set_launch_shape: the rolled kernel exists for the hopper only");
+  if (shape[3] > 0 && h->kind != REX_HUMANOID) return set_err(REX_ERR_ARG, "rex_set_launch_shape: hum_pair is a shape of the humanoid");
+  if (pair && rolled) return set_err(REX_ERR_ARG, "rex_set_launch_shape: the rolled kernel is a one-lane-per-env kernel (pair and rolled exclude each other)");
+  if (pair && !h->sp.fast) return set_err(REX_ERR_STATE, "rex_set_launch_shape: the pair split lives in the feet-only solver instantiation, which REX_FAST=0 switched off");
+  h->lanes = lanes; h->pair = pair; h->rolled = rolled; h->hum_pair = hum_pair;
+  return REX_OK;
+}
 extern "C" int rex_enable_timing(rex_t* h, int enable) {
-  if (!h) return set_err(REX_ERR_ARG, "null handle");
+  REX_ENTER(h, "rex_enable_timing");
   if (enable && h->ev0.empty()) {   // the only place events are created: rex_step never allocates
-    HIP_TRY(hipSetDevice(h->device));
     h->ev0.reserve(EV_POOL); h->ev1.reserve(EV_POOL);
     hipError_t err = hipSuccess;
     for (size_t k = 0; k < EV_POOL && err == hipSuccess; k++) {
@@ -1455,6 +1550,7 @@ extern "C" int rex_enable_timing(rex_t* h, int enable) {
 }
 extern "C" int rex_read_timing(rex_t* h, float* ms_out, int max_n) {
   if (!h || !ms_out) { set_err(REX_ERR_ARG, "rex_read_timing: null argument"); return REX_ERR_ARG; }
+  if (hipSetDevice(h->device) != hipSuccess) return set_err(REX_ERR_HIP, "rex_read_timing: hipSetDevice(%d) failed", h->device);
   int n = 0;
   const size_t pool = h->ev0.size();
   const size_t first = h->ev_n > pool ? h->ev_n - pool : 0;   // the ring keeps the last `pool` launches
@@ -1472,7 +1568,8 @@ extern "C" int rex_read_timing(rex_t* h, float* ms_out, int max_n) {
 // episode bookkeeping, lane export, side-effect-free xi draws
 // ------------------------------------------------------------------------------------------
 extern "C" int rex_get_counters_state(rex_t* h, int32_t* t, uint32_t* episode, uint8_t* done, void* stream) {
-  if (!h || !t || !episode || !done) return set_err(REX_ERR_ARG, "rex_get_counters_state: null argument");
+  REX_ENTER(h, "rex_get_counters_state");
+  if (!t || !episode || !done) return set_err(REX_ERR_ARG, "rex_get_counters_state: null argument");
   hipStream_t st = (hipStream_t)stream; const size_t B = (size_t)h->B;
   HIP_TRY(hipMemcpyAsync(t, h->dev.t, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(episode, h->dev.episode, sizeof(unsigned) * B, hipMemcpyDeviceToDevice, st));
@@ -1480,7 +1577,8 @@ extern "C" int rex_get_counters_state(rex_t* h, int32_t* t, uint32_t* episode, u
   return REX_OK;
 }
 extern "C" int rex_set_counters_state(rex_t* h, const int32_t* t, const uint32_t* episode, const uint8_t* done, void* stream) {
-  if (!h || !t || !episode || !done) return set_err(REX_ERR_ARG, "rex_set_counters_state: null argument");
+  REX_ENTER(h, "rex_set_counters_state");
+  if (!t || !episode || !done) return set_err(REX_ERR_ARG, "rex_set_counters_state: null argument");
   hipStream_t st = (hipStream_t)stream; const size_t B = (size_t)h->B;
   HIP_TRY(hipMemcpyAsync(h->dev.t, t, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(h->dev.episode, episode, sizeof(unsigned) * B, hipMemcpyDeviceToDevice, st));
@@ -1488,12 +1586,14 @@ extern "C" int rex_set_counters_state(rex_t* h, const int32_t* t, const uint32_t
   return REX_OK;
 }
 extern "C" int rex_get_aux(rex_t* h, float* aux, void* stream) {
-  if (!h || !aux) return set_err(REX_ERR_ARG, "rex_get_aux: null argument");
+  REX_ENTER(h, "rex_get_aux");
+  if (!aux) return set_err(REX_ERR_ARG, "rex_get_aux: null argument");
   if (!h->dims.n_aux) return set_err(REX_ERR_UNSUPPORTED, "this env kind keeps no auxiliary sim data");
   return copy_rows(aux, h->dev.aux, h->dims.n_aux, h->B, (hipStream_t)stream);
 }
 extern "C" int rex_set_aux(rex_t* h, const float* aux, void* stream) {
-  if (!h || !aux) return set_err(REX_ERR_ARG, "rex_set_aux: null argument");
+  REX_ENTER(h, "rex_set_aux");
+  if (!aux) return set_err(REX_ERR_ARG, "rex_set_aux: null argument");
   if (!h->dims.n_aux) return set_err(REX_ERR_UNSUPPORTED, "this env kind keeps no auxiliary sim data");
   return copy_rows(h->dev.aux, aux, h->dims.n_aux, h->B, (hipStream_t)stream);
 }
@@ -1504,9 +1604,9 @@ extern "C" int rex_set_info_buffer(rex_t* h, float* info) {
   return REX_OK;
 }
 extern "C" int rex_export_lane(rex_t* h, int64_t lane, float* qpos, float* qvel, float* xi) {
-  if (!h || !qpos || !qvel || !xi) return set_err(REX_ERR_ARG, "rex_export_lane: null argument");
+  REX_ENTER(h, "rex_export_lane");
+  if (!qpos || !qvel || !xi) return set_err(REX_ERR_ARG, "rex_export_lane: null argument");
   if (lane < 0 || lane >= h->B) return set_err(REX_ERR_ARG, "rex_export_lane: lane %lld outside [0, %lld)", (long long)lane, h->B);
-  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   const size_t B = (size_t)h->B;   // SoA rows: element `lane` of every row (a strided 2-D copy)
   HIP_TRY(hipMemcpy2D(qpos, sizeof(float), h->dev.qpos + lane, sizeof(float) * B, sizeof(float), h->dims.nq, hipMemcpyDeviceToHost));
@@ -1524,10 +1624,10 @@ __global__ void __launch_bounds__(64) sample_task_kernel(DevState s, DRParams dr
   sample_task(dr, s.seed ^ SAMPLE_SEED_SALT, (unsigned long long)(s.env_offset + i), draw_index * 256ull, out, (size_t)s.B, i, s.counters);
 }
 extern "C" int rex_sample_task(rex_t* h, float* xi_out, uint64_t draw_index, void* stream) {
-  if (!h || !xi_out) return set_err(REX_ERR_ARG, "rex_sample_task: null argument");
+  REX_ENTER(h, "rex_sample_task");
+  if (!xi_out) return set_err(REX_ERR_ARG, "rex_sample_task: null argument");
   if (h->dr.type == REX_DR_NONE) return set_err(REX_ERR_STATE,
       "sampling value of random env needs to be set before using sample_task() or set_random_task()");   // random_env.py:201
-  HIP_TRY(hipSetDevice(h->device));
   DRParams dr = h->dr;
   for (int k = 0; k < dr.dim; k++) dr.map[k] = k;   // task order, not the kernels' full xi block
   hipLaunchKernelGGL(sample_task_kernel, dim3(grid_for(h)), dim3(lanes_of(h)), 0, (hipStream_t)stream, h->dev, dr, (unsigned long long)draw_index, xi_out);

@@ -30,12 +30,40 @@ WAVE_ENVS = 64   # envs per wavefront of the step kernels at their widest (one l
                  # the solver instantiation is picked per wave
 
 
+def shape_for_batch(kind, batch, simds=1024):
+    """The launch shape rex_create picks for `batch` envs of `kind` on a GPU with `simds` SIMDs (MI355X: 1 024): the rule of
+    rex_hip.hip::create_body restated for the host (tests/test_gpu_api.py::test_launch_shape_follows_the_batch holds the two together)."""
+    planar = kind in ("hopper", "halfcheetah", "walker2d")
+    return dict(lanes=64 if batch > 32 * simds else 32, pair=bool(planar and batch <= 32 * simds),
+                rolled=bool(kind == "hopper" and batch > 64 * simds), hum_pair=(kind == "humanoid"))
+
+
+def pin_global_shape(env, global_batch, simds=None):
+    """Give a shard the launch shape its GLOBAL batch would get on one GPU (rex_set_launch_shape).  rex_create picks the shape from
+    the per-GPU batch: 65 536 envs on one GPU run one lane per env, the same envs split over two GPUs two lanes per env, and the two
+    kernels round differently.  Pinned, an index-sharded run reproduces the single-GPU trajectories bit for bit (given shard
+    boundaries on whole waves: shard_strong); unpinned, every shard runs the fastest shape for its own size and agrees with the
+    single-GPU run to fp32 rounding only."""
+    if simds is None:
+        import torch
+        simds = 4 * torch.cuda.get_device_properties(env.device).multi_processor_count
+    sh = shape_for_batch(env.kind, int(global_batch), simds)
+    kw = dict(lanes=sh["lanes"])
+    if env.kind in ("hopper", "halfcheetah", "walker2d"):
+        kw.update(pair=sh["pair"])
+    if env.kind == "hopper":
+        kw.update(rolled=sh["rolled"])
+    return env.set_launch_shape(**kw)
+
+
 def shard_strong(global_batch, rank, world, align=WAVE_ENVS):
     """(env_offset, batch) of this rank when a fixed global batch is split.  Shard boundaries fall on multiples of `align`
-    envs (one wavefront of the step kernels) wherever the batch allows it, so that every wave holds the same envs as in the
-    single-GPU run and an index-sharded run reproduces it bit for bit under the default solver knobs too (the arithmetic of
-    a lane depends on which instantiation its WAVE picks); the remainder goes to the low ranks, the last rank takes what
-    is left."""
+    envs (one wavefront of the step kernels at its widest) wherever the batch allows it, so that every wave holds the same envs
+    as in the single-GPU run.  Everything the RNG decides is bit-identical under any split.  The ARITHMETIC of a lane also depends
+    on which solver instantiation its wave picks and on the launch shape rex_create derives from the PER-GPU batch, so an
+    index-sharded run reproduces the single-GPU trajectories bit for bit only when the shards also run the global batch's shape
+    (`pin_global_shape`, `bench.py --pin-shape`) or under REX_FAST=0; otherwise lanes agree to fp32 rounding.  The remainder goes to
+    the low ranks, the last rank takes what is left."""
     align = max(int(align), 1)
     blocks, tail = divmod(global_batch, align)
     if blocks < world:           # fewer whole waves than ranks: plain split
@@ -99,9 +127,11 @@ class StepCounter:
         self.local = 0            # env-steps of this rank
         self.n_calls = 0
         self.last_global = 0      # result of the most recent reduction that total() / poll() has read back
-        self._bufs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
         self._works = [None, None]
         self._side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        with self._ctx():         # staging buffers are created AND zero-filled on the side stream: every later fill_ / all_reduce on
+            self._bufs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]   # them is ordered behind that fill
+        self._polled = [True, True]   # staging buffer already folded into last_global
         self.reductions = 0
 
     def add(self, env_steps):
@@ -121,8 +151,23 @@ class StepCounter:
                 self._works[k].wait()
             self._bufs[k].fill_(self.local)
             self._works[k] = self._dist.all_reduce(self._bufs[k], op=self._dist.ReduceOp.SUM, async_op=True)
+        self._polled[k] = False
         self.reductions += 1
         return k
+
+    def poll(self):
+        """Non-blocking: the lagging global count.  Folds into `last_global` every reduction that has COMPLETED since the last call
+        (`work.is_completed()`; nothing is waited for, the compute stream is not touched) and returns it; 0 until the first one lands."""
+        if self._dist is None:
+            self.last_global = self.local
+            return self.last_global
+        for k in (0, 1):
+            w = self._works[k]
+            if w is not None and not self._polled[k] and w.is_completed():
+                with self._ctx():
+                    self.last_global = max(self.last_global, int(self._bufs[k].item()))
+                self._polled[k] = True
+        return self.last_global
 
     def total(self):
         if self._dist is None:
@@ -130,7 +175,8 @@ class StepCounter:
         k = self._issue()
         with self._ctx():
             self._works[k].wait()
-            self.last_global = int(self._bufs[k].item())   # the only read-back: after the timed region
+            self.last_global = int(self._bufs[k].item())   # the only blocking read-back: after the timed region
+        self._polled[k] = True
         return self.last_global
 
 

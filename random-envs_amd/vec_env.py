@@ -412,10 +412,18 @@ class VecRandomEnv(DRConfig):
         return dict(nonfinite=out[0], gaussian_fail=out[1], solver_capped=out[2], overflow=out[3])
 
     def launch_shape(self):
-        """What rex_create picked for this handle from its batch and the GPU's SIMD count."""
+        """What rex_create picked for this handle from its batch and the GPU's SIMD count, or what set_launch_shape pinned."""
         out = (ctypes.c_int32 * 4)()
         _native.check(self._L.rex_get_launch_shape(self._h, out))
         return dict(lanes=int(out[0]), pair=bool(out[1]), rolled=bool(out[2]), hum_pair=bool(out[3]))
+
+    def set_launch_shape(self, lanes=None, pair=None, rolled=None, hum_pair=None):
+        """Pin the launch shape of this handle (rex_set_launch_shape; None keeps a field).  Two runs agree bit for bit only under the
+        same shape, so `sharding.pin_global_shape` gives every shard of a split batch the shape its GLOBAL batch gets on one GPU."""
+        f = lambda v: -1 if v is None else int(v)
+        arr = (ctypes.c_int32 * 4)(f(lanes), f(pair), f(rolled), f(hum_pair))
+        _native.check(self._L.rex_set_launch_shape(self._h, arr))
+        return self.launch_shape()
 
     def enable_timing(self, every=1):
         """HIP-event duration of every `every`-th step kernel launch (True / 1: all of them, 0 / False: off)."""

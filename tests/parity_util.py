@@ -44,23 +44,16 @@ def assert_done_explained(done_gpu, done_ref, margins, eps, label=""):
 def lanes_per_block(n):
     """Launch shape of the handles created inside: REX_LANES is read once in rex_create (None = the default rule:
     32-lane blocks up to 32 768 envs, 64-lane blocks -- and the > 64 KB dynamic-LDS opt-in of the humanoid's one-lane kernels -- past that)."""
-    old = os.environ.get("REX_LANES")
-    try:
-        if n is None:
-            os.environ.pop("REX_LANES", None)
-        else:
-            os.environ["REX_LANES"] = str(n)
+    with create_knobs(REX_LANES=n):
         yield
-    finally:
-        if old is None:
-            os.environ.pop("REX_LANES", None)
-        else:
-            os.environ["REX_LANES"] = old
 
 
 @contextlib.contextmanager
 def create_knobs(**knobs):
-    """Environment knobs librex reads once in rex_create (REX_FAST, REX_LANES, ...) for the handles created inside."""
+    """Environment knobs librex reads once in rex_create (REX_FAST, REX_LANES, ...) for the handles created inside.  The library honours a
+    knob only beside REX_ALLOW_TUNING=1 and refuses to create a handle otherwise (include/rex.h), so that rides along while one is set."""
+    if any(v is not None for v in knobs.values()):
+        knobs = dict(knobs, REX_ALLOW_TUNING=1)
     old = {k: os.environ.get(k) for k in knobs}
     try:
         for k, v in knobs.items():

@@ -1,6 +1,7 @@
 """C-ABI / VecRandomEnv behaviour: ragged and tiny batches, masks, error paths, determinism,
 state helpers, the SB3-style adapter."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -184,3 +185,70 @@ def test_launch_shape_follows_the_batch(torch_mod):
     env = rex.make("RandomCartPole-v0", batch=256, autoreset=False)
     assert env.launch_shape() == dict(lanes=32, pair=False, rolled=False, hum_pair=False)
     env.close()
+
+
+def test_stray_knobs_are_refused_and_shapes_are_pinned_through_the_abi(torch_mod):
+    """A tuning variable set WITHOUT REX_ALLOW_TUNING=1 makes rex_create fail loudly (REX_ERR_STATE naming the variable) instead of silently
+    changing the solver; with it the knob is honoured.  rex_set_launch_shape pins the shape per handle: round trip, -1 keeps a field, shapes an env
+    kind has no kernel for are REX_ERR_ARG."""
+    import random_envs_amd as rex
+    from random_envs_amd import _native
+    from parity_util import create_knobs
+    for k, v in (("REX_FAST", "0"), ("REX_CORR", "0"), ("REX_PAIR", "0"), ("REX_LANES", "64"), ("REX_HUM_ITERS", "5"), ("REX_DIAG_NOCONTACT", "1")):
+        os.environ.pop("REX_ALLOW_TUNING", None)
+        os.environ[k] = v
+        try:
+            with pytest.raises(_native.RexError, match=k):
+                rex.make("RandomHopper-v0", batch=64, autoreset=False)
+        finally:
+            os.environ.pop(k)
+    with create_knobs(REX_HUM_ITERS=5):   # allowed to tune, but the product build has no such knob: still refused
+        with pytest.raises(_native.RexError, match="REX_TUNING"):
+            rex.make("RandomHumanoid-v0", batch=64, autoreset=False)
+    env = rex.make("RandomHopper-v0", batch=256, autoreset=False)
+    assert env.launch_shape() == dict(lanes=32, pair=True, rolled=False, hum_pair=False)
+    assert env.set_launch_shape(lanes=64, pair=False) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
+    assert env.set_launch_shape(rolled=True) == dict(lanes=64, pair=False, rolled=True, hum_pair=False)
+    assert env.set_launch_shape() == dict(lanes=64, pair=False, rolled=True, hum_pair=False)       # all -1: nothing changes
+    for bad in (dict(lanes=48), dict(pair=True), dict(hum_pair=True)):                              # pair + rolled / not a humanoid / lanes
+        with pytest.raises(ValueError):
+            env.set_launch_shape(**bad)
+    env.close()
+    env = rex.make("RandomWalker2d-v0", batch=64, autoreset=False)
+    with pytest.raises(ValueError):
+        env.set_launch_shape(rolled=True)
+    env.close()
+
+
+def test_pinned_shards_reproduce_a_single_gpu_batch_past_the_pair_limit(torch_mod):
+    """rex_create picks the launch shape from the PER-GPU batch, so 65 536 envs on one GPU (one lane per env) and the same envs split
+    over two GPUs (two lanes per env) round differently.  With sharding.pin_global_shape every shard runs the global batch's shape and the split
+    reproduces the single-GPU trajectories bit for bit; un-pinned they agree to fp32 rounding (and then diverge chaotically)."""
+    import random_envs_amd as rex
+    from random_envs_amd import sharding
+    torch = torch_mod
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    B, steps = 64 * simds, 6
+    assert sharding.shape_for_batch("hopper", B, simds) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
+    g = torch.Generator().manual_seed(3)
+    acts = (torch.rand(steps, B, 3, generator=g) * 2 - 1)
+
+    def run(off, n, pin):
+        env = rex.make("RandomHopper-v0", batch=n, seed=7, env_offset=off)
+        if pin:
+            sharding.pin_global_shape(env, B)
+        shape = env.launch_shape()
+        env.set_dr_distribution("uniform", [3.0, 4.0, 3.5, 4.5, 2.2, 3.2, 4.5, 5.5]); env.set_dr_training(True)
+        env.reset()
+        outs = [tuple(x.clone() for x in env.step(acts[t, off:off + n].cuda())[:3]) for t in range(steps)]
+        env.close()
+        return shape, outs
+    shape_full, full = run(0, B, False)
+    off, n = sharding.shard_strong(B, 1, 2)
+    shape_pin, pinned = run(off, n, True)
+    shape_free, free = run(off, n, False)
+    assert shape_full == shape_pin == dict(lanes=64, pair=False, rolled=False, hum_pair=False) and shape_free["pair"]
+    for (o, r, d), (o1, r1, d1) in zip(full, pinned):
+        assert torch.equal(o[off:off + n], o1) and torch.equal(r[off:off + n], r1) and torch.equal(d[off:off + n], d1)
+    o, o2 = full[0][0][off:off + n], free[0][0]
+    assert not torch.equal(o, o2) and (o - o2).abs().max() < 1e-3   # another kernel: equal to rounding after one step, not bit for bit

@@ -22,7 +22,9 @@ def _run(*extra, launcher=()):
 def test_headline_line_contract():
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     d = _run("--steps", "60", "--warmup", "10", "--batch", "4096", "--cpu-sample-steps", "2")
-    assert d["metric"] == base["metric"] and d["unit"] == "env-steps/s"
+    # (a 4 096-env line names its own quantity; BASELINE.json's string is asserted on the 32 768-env line below)
+    assert d["metric"] == "env-steps/sec at batch 4096, RandomHopper-v0, 1 MI355X; % HBM roofline" and d["unit"] == "env-steps/s"
+    assert base["metric"].startswith("env-steps/sec at batch 32768, RandomHopper-v0")
     assert d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "RandomHopper-v0" in d["config"]["workload"] and "model" not in d["config"]
@@ -72,6 +74,8 @@ def test_driver_command_reports_the_steady_state():
     short = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
     long_ = _run("--gpus", "1", "--steps", "400", "--warmup", "50", "--no-cpu-baseline")
     assert short["config"]["global_batch"] == 32768
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert short["metric"] == base["metric"] and long_["metric"] == base["metric"]   # the north-star line carries BASELINE.json's metric verbatim
     assert abs(short["value"] - long_["value"]) < 0.10 * long_["value"], (short["value"], long_["value"])
     for d in (short, long_):
         r = d["roofline"]
@@ -100,6 +104,8 @@ def test_two_rank_rehearsal_on_one_gpu():
     strong = _run(*common, "--batch", "4096", "--scaling", "strong", launcher=launcher)
     assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 4096
     assert "batch 2048 per GPU" in strong["config"]["workload"]
+    assert strong["metric"] == "env-steps/sec at batch 4096 in total, RandomHopper-v0, 2 MI355X; % HBM roofline"
+    assert weak["metric"] == "env-steps/sec at batch 4096 per GPU, RandomHopper-v0, 2 MI355X; % HBM roofline"
 
 
 def test_self_launched_two_ranks_on_one_gpu():

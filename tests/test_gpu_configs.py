@@ -236,19 +236,23 @@ def test_bench_gpus_n_starts_its_own_ranks():
 
 
 @pytest.mark.parametrize("cfg,eid,B,kernel,nbytes", [
-    ("C2", "RandomHopper-v0", 4096, "HopperSpec", 173), ("C3", "RandomHalfCheetahNoisy-v0", 16384, "HalfCheetahSpec", 273),
+    ("C1", "RandomCartPole-v0", 1, "cartpole_step_kernel", 73), ("C2", "RandomHopper-v0", 4096, "HopperSpec", 173), ("C3", "RandomHalfCheetahNoisy-v0", 16384, "HalfCheetahSpec", 273),
     ("C4", "RandomWalker2d-v0", 8192, "Walker2dSpec", 293), ("C5", "RandomHumanoid-v0", 32768, "humanoid_pair_step_kernel", 2073)])
 def test_bench_config_lines(cfg, eid, B, kernel, nbytes):
-    """`bench.py --config C2..C5`: SURVEY 8(d)'s inputs, each line with the roofline of its own kernel and (C2) the CPU leg
-    on the GPU leg's settled states."""
-    extra = () if cfg == "C2" else ("--no-cpu-baseline",)
+    """`bench.py --config C1..C5`: SURVEY 8(d)'s inputs, each line with the roofline of its own kernel, a `metric` that names what the
+    line measured (BASELINE.json's string belongs to the north-star line alone) and (C1, C2) the CPU leg on the GPU leg's settled states."""
+    extra = () if cfg in ("C1", "C2") else ("--no-cpu-baseline",)
     d = _bench("--config", cfg, "--steps", "24", "--warmup", "4", "--settle", "60", "--cpu-sample-steps", "2", *extra)
+    assert d["metric"] == "env-steps/sec at batch %d, %s, 1 MI355X; %% HBM roofline" % (B, eid)
+    assert d["metric"] != json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     w = d["config"]["workload"]
     assert w.startswith(cfg + ": " + eid) and "batch %d per GPU" % B in w and cfg in d["config"]["baseline_config"]
     r = d["roofline"]
     assert kernel in r["kernel"] and r["bytes_per_env_step"] == nbytes and r["kernel_launches_timed"] >= 64
     assert abs(r["achieved"] - nbytes * B / (r["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert d["nonfinite_lanes"] == 0 and d["overflow_lanes"] == 0
-    if cfg == "C2":
+    if cfg in ("C1", "C2"):
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and "settled" in c["sample"] and c["value"] > 0 and c["cores"] >= 1
+    if cfg == "C1":   # one env, one core: the reference's usage shape (test_random_policy.py:25-32) beside the GPU's step latency
+        assert c["cores"] == 1 and c["one_env_one_core"] > 0 and "U{0,1}" in w and "no DR" in w

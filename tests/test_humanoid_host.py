@@ -149,3 +149,49 @@ def test_second_broad_phase_test_never_changes_a_result(hh):
             assert np.array_equal(qa1, qa2), i
             ncon += int(i1[0])
     assert ncon > 4 * n      # the sample is contact-rich (capsule-capsule pairs included)
+
+
+def test_fp32_host_engine_at_the_device_sweep_schedule(hh):
+    """on the device the PGS stopping rule is evaluated every REX_PGS_CHECK-th (10th) sweep, in the host harness every sweep.  A harness
+    built with -DREX_PGS_CHECK_HOST runs the fp32 engine at the DEVICE's schedule: sweep counts are then the every-sweep counts rounded up to
+    the next multiple of 10 (never past MuJoCo's cap of 50), and one env step still agrees with the fp64 oracle within the fp32 tolerance the
+    GPU tests use -- the extra sweeps act on a system already converged to the tolerance."""
+    so3 = os.path.join(HERE, "host_harness", "_build_humanoid_host_devsched.so")
+    if not os.path.exists(so3) or any(os.path.getmtime(d) > os.path.getmtime(so3) for d in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DREX_PGS_CHECK_HOST", "-o", so3, SRC])
+    hd = ctypes.CDLL(so3)
+    rng = np.random.RandomState(3)
+    nom = np.array(SPECS["humanoid"].nominal_task)
+    I = ctypes.POINTER(ctypes.c_int)
+    seen_rows = 0; rounded = 0
+    for k in range(80):
+        q = np.array([0, 0, 1.4, 1, 0, 0, 0] + [0] * 17, dtype=float); q[7:] += rng.uniform(-.6, .6, 17); q[2] = rng.uniform(0.7, 1.35)
+        qq = np.array([1, 0, 0, 0]) + rng.uniform(-.3, .3, 4); q[3:7] = qq / np.linalg.norm(qq)
+        v = rng.uniform(-2, 2, 23); a = rng.uniform(-.4, .4, 17); xi = nom * rng.uniform(.8, 1.2, 30)
+        out = []
+        for h in (hh, hd):
+            qa = np.zeros(23); M = np.zeros((23, 23)); info = np.zeros(4, dtype=np.int32)
+            h.hh_forward(1, _p(q), _p(v), _p(a), _p(xi), _p(qa), _p(M), info.ctypes.data_as(I))
+            out.append((qa, info.copy()))
+        (qa1, i1), (qa2, i2) = out
+        assert i1[0] == i2[0] and i1[1] == i2[1] and i2[3] == 0
+        if i1[1] == 0 or i1[1] > 21:      # no rows / the scratch-row path (which checks every sweep on the device too)
+            continue
+        seen_rows += 1
+        assert i2[2] == min(50, -(-i1[2] // 10) * 10), (k, i1, i2)      # ceil to the next multiple of 10, capped at 50
+        rounded += int(i2[2] != i1[2])
+        assert np.abs(qa1 - qa2).max() <= 2e-5 * (1 + np.abs(qa1).max()), (k, np.abs(qa1 - qa2).max())
+    assert seen_rows >= 20 and rounded >= 5, (seen_rows, rounded)
+    # a whole env step at the device schedule against the fp64 oracle: the GPU tests' fp32 tolerances
+    n = 200
+    q, v, a, xi = _states(n, 1)
+    ref = oracle_humanoid_step(q, v, a, xi)
+    UB = ctypes.POINTER(ctypes.c_ubyte)
+    qs, vs, as_, xs = [np.ascontiguousarray(x.T) for x in (q, v, a, xi)]
+    qo = np.zeros_like(qs); vo = np.zeros_like(vs); obs = np.zeros((376, n)); r = np.zeros(n); d = np.zeros(n, dtype=np.uint8)
+    xo = np.zeros((14, n)); ov = np.zeros(n, dtype=np.int32)
+    hd.hh_step(1, n, _p(qs), _p(vs), _p(as_), _p(xs), None, _p(qo), _p(vo), _p(obs), _p(r), d.ctypes.data_as(UB), _p(xo), ov.ctypes.data_as(I))
+    ev = np.abs(vo.T - ref["qvel"]).max(1) / (1 + np.abs(ref["qvel"]).max(1))
+    eo = np.abs(obs.T - ref["obs"]).max(1) / (1 + np.abs(ref["obs"]).max(1))
+    assert ev.max() < 5e-4 and eo.max() < 2e-4 and ov.sum() == 0, (ev.max(), eo.max())
+    assert np.abs(r - ref["reward"]).max() < 2e-3

@@ -25,11 +25,18 @@ lag = []
 for k in range(25):
     ctr.add(b + rank)
     lag.append(ctr.last_global)
+import time
+polled = 0
+for _ in range(200):                       # poll(): non-blocking, folds in whatever has completed (here: the in-loop reductions)
+    polled = ctr.poll()
+    if polled >= 24 * (2 * b + 1):
+        break
+    time.sleep(0.01)
 atotal = ctr.total()
 tmax2 = sharding.reduce_max(1.0 + rank, torch.device("cpu"))
 sharding.barrier()
 print(json.dumps(dict(rank=rank, off=off, so=so, sb=sb, total=total, tmax=tmax, atotal=atotal, nred=ctr.reductions,
-                      lag=lag[-1], tmax2=tmax2)), flush=True)
+                      lag=lag[-1], polled=polled, tmax2=tmax2)), flush=True)
 sharding.shutdown()
 """
 
@@ -62,9 +69,12 @@ def test_two_rank_gloo_sharding_and_counter(tmp_path):
     # stepping (a read-back is a blocking device-to-host copy: it would drain the launch queue every `every` steps)
     assert all(d["atotal"] == 25 * (2 * 32768 + 1) and d["nred"] == 4 for d in outs)
     assert all(d["lag"] == 0 for d in outs)
-    # strong split covers the global batch exactly once, the boundary on a whole wavefront (32 envs)
+    # poll() is the lagging running total: the third in-loop reduction (after 24 steps) once it has completed, never a blocking wait
+    assert all(d["polled"] == 24 * (2 * 32768 + 1) for d in outs)
+    # strong split covers the global batch exactly once, the boundary on a whole wavefront of the widest launch shape (64 envs; bit-for-bit
+    # reproduction of the single-GPU run additionally needs the same launch shape: sharding.pin_global_shape, tests/test_gpu_api.py)
     assert outs[0]["so"] == 0 and outs[1]["so"] == outs[0]["sb"] and outs[0]["sb"] + outs[1]["sb"] == 32769
-    assert outs[1]["so"] % 32 == 0
+    assert outs[1]["so"] % 64 == 0
 
 
 def test_shard_strong_partition():
@@ -75,6 +85,20 @@ def test_shard_strong_partition():
             off, b = sharding.shard_strong(32768 + 5, r, world)
             cover += list(range(off, off + b))
         assert cover == list(range(32768 + 5))
-        # every boundary on a whole wavefront of the step kernels: sharded runs reproduce the single-GPU waves
+        # every boundary on a whole wavefront of the step kernels: sharded runs hold the single-GPU run's waves
         assert all(sharding.shard_strong(32768 + 5, r, world)[0] % sharding.WAVE_ENVS == 0 for r in range(world))
     assert sharding.shard_strong(40, 1, 4) == (10, 10)    # fewer whole waves than ranks: plain split
+
+
+def test_shape_for_batch_restates_rex_create():
+    """The host restatement of rex_create's launch-shape rule (what pin_global_shape pins a shard to); the GPU test
+    test_launch_shape_follows_the_batch holds the library to the same table."""
+    from random_envs_amd import sharding
+    f = sharding.shape_for_batch
+    assert f("hopper", 32768) == dict(lanes=32, pair=True, rolled=False, hum_pair=False)
+    assert f("hopper", 32769) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
+    assert f("hopper", 65537) == dict(lanes=64, pair=False, rolled=True, hum_pair=False)
+    assert f("walker2d", 65537) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
+    assert f("humanoid", 70000) == dict(lanes=64, pair=False, rolled=False, hum_pair=True)
+    assert f("cartpole", 5) == dict(lanes=32, pair=False, rolled=False, hum_pair=False)
+    assert f("halfcheetah", 4096, simds=64) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
