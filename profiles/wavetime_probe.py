@@ -46,6 +46,7 @@ for eid in sys.argv[1:] or ["RandomHopper-v0"]:
     top = w.argmax(1)   # the slowest wave of each launch: what the launch waits for
     for k, nm in enumerate(names): print("     %-13s %8.1f %8.1f   slowest wave of each launch: mean %8.1f  min %8.1f  max %8.1f" %
                                          (nm, I[..., k][fast].mean(), I[..., k][slow].mean(), I[np.arange(len(top)), top, k].mean(), I[np.arange(len(top)), top, k].min(), I[np.arange(len(top)), top, k].max()))
+    print("   per wave-step counts, mean over ALL waves: " + "  ".join("%s %.2f" % (nm, I[..., k].mean()) for k, nm in enumerate(names)))
     srt = np.sort(w, 1)
     print("   per launch: slowest wave %.0f, 2nd %.0f, 5th %.0f, 10th %.0f, 20th %.0f, 50th %.0f cycles (means over the launches)" %
           tuple(srt[:, -k].mean() for k in (1, 2, 5, 10, 20, 50)))

@@ -1118,6 +1118,460 @@ REX_HD SolveStats solve_newton_rolled(const T (&M)[S::NV][S::NV], const T (&qfrc
   return st;
 }
 
+// ---- the general instantiation as a LIST solver (GEN = 2 of forward() / substep()) -----------------------------------------------------
+// The unrolled general instantiation keeps 12 values per floor slot in registers for all 2 NG slots at once (96 / 168 / 192 registers for
+// hopper / walker2d / half-cheetah) and spends a wave-uniform branch per slot and pass; being in the same kernel it taxes the feet-only path
+// (its long-lived state gets AGPR homes: hopper 0.0885 -> 0.0788 ms with the general instantiations compiled out), and for walker2d and the
+// half-cheetah it IS the cost centre (a wave with a thigh on the floor is what a launch waits for; 69 % of the half-cheetah's wave-solves).
+// Here the same primal Newton solve walks a runtime LIST of the contact units some lane of the wave has inside the margin:
+//   * a unit is one capsule END (slot 2 g + end).  With two lanes per env (PAIR) lane parity = end, exactly as in the feet-only path: each
+//     lane runs the per-unit part of every pass for ITS end of every listed capsule and the partial gradients / Hessians / phi' sums and
+//     edge bits are exchanged with DPP (pair_xchg); with one lane per env a lane walks both ends (units = slots).
+//   * per-unit data (contact point, D, reference accelerations, friction, J qacc, J sr) sits in a per-lane column of LDS (SlotMem: field-major,
+//     lane-interleaved, conflict-free; a plain array on the host) and is read where a pass needs it: nothing per unit is live in registers
+//     between passes, so the solver's register footprint does not depend on NG.
+//   * the hinge columns of a unit's point Jacobian are rebuilt from (contact point, joint anchors) with a SCALAR ancestor mask of the unit's body
+//     (anc_pack: 8 bits per capsule): non-ancestors get weight 0 instead of a compile-time skip.
+//   * the one-group Woodbury correction of the feet-only instantiation works here too (the toggled unit is a per-lane runtime index into the
+//     column) -- the unrolled general instantiation never had room for it.
+enum SlotField { SF_PX = 0, SF_PZ, SF_D, SF_AN, SF_AT, SF_MU, SF_LT, SF_LN, SF_LVT, SF_LVN, SF_COUNT };
+enum SelfField { SR_PX = 0, SR_PZ, SR_NX, SR_NZ, SR_D, SR_AREF, SR_JQ, SR_JV, SR_COUNT };   // a capsule-capsule row: contact point, normal, D, aref, J qacc, J sr
+template <class T, class S, bool PAIR>
+struct SlotMem {
+  static constexpr int NUNIT = PAIR ? S::NG : 2 * S::NG;
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr int STRIDE = 64;          // lanes of a workgroup of the step kernels that use it
+#else
+  static constexpr int STRIDE = 1;
+#endif
+  static constexpr int NSROW = S::NSELF > 0 ? 2 * S::NSELF : 0;            // capsule-capsule rows (hopper): SR_COUNT words each, behind the units
+  static constexpr int SELF_BASE = SF_COUNT * NUNIT * STRIDE;
+  static constexpr int WORDS = (SF_COUNT * NUNIT + SR_COUNT * NSROW) * STRIDE;   // per workgroup (device) / per env (host)
+  T* p;                                      // this lane's word of (field 0, unit 0)
+  REX_HD T* unit(unsigned u) const { return p + u * unsigned(STRIDE); }
+  static constexpr int off(int f) { return f * NUNIT * STRIDE; }
+  REX_HD T* srow(unsigned r) const { return p + SELF_BASE + r * unsigned(STRIDE); }
+  static constexpr int soff(int f) { return f * NSROW * STRIDE; }
+};
+template <class S> constexpr unsigned long long anc_pack() {   // byte g: bit j set <=> body j is geom g's body or an ancestor of it
+  unsigned long long r = 0;
+  for (int g = 0; g < S::NG; g++) { unsigned m = 0; for (int j = 0; j < S::NB; j++) if (is_anc_or_self<S>(j, S::geom_body[g])) m |= 1u << j; r |= (unsigned long long)m << (8 * g); }
+  return r;
+}
+static_assert(HopperSpec::NB <= 8 && Walker2dSpec::NB <= 8 && HalfCheetahSpec::NB <= 8 && HalfCheetahSpec::NG <= 8, "anc_pack: 8 bodies x 8 capsules");
+template <class S> REX_HD unsigned anc_of_geom(unsigned g) { constexpr unsigned long long A = anc_pack<S>(); return (unsigned)(A >> (8u * g)) & 0xffu; }   // (constexpr local: evaluated by the compiler, not walked at run time)
+// Root paths of the tree's leaves (hopper: one, {0,1,2,3}; walker2d / half-cheetah: two, {0,1,2,3} and {0,4,5,6}): a unit's body lies on one of
+// them, so its Jacobian columns, dot products and Hessian block only run over that path's bodies -- picked by a scalar branch per unit.
+template <class S> constexpr unsigned leaf_path(int which) {
+  int seen = 0;
+  for (int b = 0; b < S::NB; b++) {
+    bool leaf = true;
+    for (int c = 0; c < S::NB; c++) if (S::parent[c] == b) leaf = false;
+    if (!leaf) continue;
+    if (seen++ == which) { unsigned m = 0; for (int j = 0; j < S::NB; j++) if (is_anc_or_self<S>(j, b)) m |= 1u << j; return m; }
+  }
+  return 0u;
+}
+template <class S> constexpr int leaf_paths() { int n = 0; while (n < 4 && leaf_path<S>(n) != 0u) n++; return n; }
+static_assert(leaf_paths<HopperSpec>() == 1 && leaf_paths<Walker2dSpec>() == 2 && leaf_paths<HalfCheetahSpec>() == 2, "list solver: one or two leaf paths");
+// f(IC<path mask>) for the leaf path that holds every body of `anc` (wave-uniform choice)
+template <class S, class F> REX_HD void on_path(unsigned anc, F&& f) {
+  constexpr unsigned P0 = leaf_path<S>(0);
+  if constexpr (leaf_paths<S>() == 1) { (void)anc; f(IC<int(P0)>{}); }
+  else { constexpr unsigned P1 = leaf_path<S>(1); if ((anc & ~P0) != 0u) f(IC<int(P1)>{}); else f(IC<int(P0)>{}); }
+}
+// hinge columns of the point Jacobian of a point on the body with ancestor mask `anc`, over the bodies of path SUB (zero for non-ancestors)
+template <class T, class S, unsigned SUB>
+REX_HD void list_jac(const Kin<T, S>& K, T px, T pz, unsigned anc, T (&jt)[S::NB], T (&jn)[S::NB]) {
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ;
+    if constexpr ((SUB >> j) & 1u) {
+      const T w = ((anc >> j) & 1u) ? T(S::sgn[j]) : T(0);
+      jt[j] = w * (pz - K.A[j][1]); jn[j] = -(w * (px - K.A[j][0])); } });
+}
+template <class T, class S, unsigned SUB>
+REX_HD void list_dot(const T (&jt)[S::NB], const T (&jn)[S::NB], const T (&x)[S::NV], T& t, T& n) {
+  t = x[0]; n = x[1];
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; if constexpr ((SUB >> j) & 1u) { t += jt[j] * x[j + 2]; n += jn[j] * x[j + 2]; } });
+}
+template <class T, class S, unsigned SUB>
+REX_HD void list_accum(const T (&jt)[S::NB], const T (&jn)[S::NB], T ft, T fn, T (&g)[S::NV]) {
+  g[0] += ft; g[1] += fn;
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; if constexpr ((SUB >> j) & 1u) g[j + 2] += jt[j] * ft + jn[j] * fn; });
+}
+template <class T, class S, unsigned SUB>
+REX_HD void list_hess(const T (&jt)[S::NB], const T (&jn)[S::NB], T ctt, T cnt, T cnn, T (&H)[S::NV][S::NV]) {
+  T wt[S::NB], wn[S::NB];
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; if constexpr ((SUB >> j) & 1u) { wt[j] = ctt * jt[j] + cnt * jn[j]; wn[j] = cnt * jt[j] + cnn * jn[j]; } });
+  H[0][0] += ctt; H[1][0] += cnt; H[1][1] += cnn;                       // (ut, un) of the root slides: (1, 0), (0, 1)
+  static_for<0, S::NB>([&](auto AA) { constexpr int a = AA;
+    if constexpr ((SUB >> a) & 1u) {
+      H[a + 2][0] += wt[a]; H[a + 2][1] += wn[a];
+      static_for<0, a + 1>([&](auto BB) { constexpr int b = BB;
+        if constexpr (((SUB >> b) & 1u) && dof_coupled<S>(a + 2, b + 2)) H[a + 2][b + 2] += wt[a] * jt[b] + wn[a] * jn[b]; }); } });
+}
+// capsule-capsule rows in the list solver: row = n . (J_b - J_a) at the contact point; the root slides cancel and hinge j carries
+// sgn_j ([j on b's root path] - [j on a's]) (n_x r_z - n_z r_x).  Ancestor masks of the two bodies of self pair q: bytes 2 q, 2 q + 1.
+template <class S> constexpr unsigned long long self_pack() {
+  unsigned long long r = 0;
+  for (int q = 0; q < S::NSELF; q++) {
+    unsigned ma = 0, mb = 0;
+    for (int j = 0; j < S::NB; j++) { if (is_anc_or_self<S>(j, S::geom_body[S::self_a[q]])) ma |= 1u << j; if (is_anc_or_self<S>(j, S::geom_body[S::self_b[q]])) mb |= 1u << j; }
+    r |= (unsigned long long)ma << (16 * q); r |= (unsigned long long)mb << (16 * q + 8);
+  }
+  return r;
+}
+template <class T, class S>
+REX_HD void self_row(const Kin<T, S>& K, T px, T pz, T nx, T nz, unsigned r, T (&row)[S::NB]) {
+  constexpr unsigned long long A = self_pack<S>();
+  const unsigned ma = (unsigned)(A >> (16u * (r >> 1))) & 0xffu, mb = (unsigned)(A >> (16u * (r >> 1) + 8u)) & 0xffu;
+  static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ;
+    const T w = T(S::sgn[j]) * (T(int((mb >> j) & 1u)) - T(int((ma >> j) & 1u)));
+    row[j] = w * (nx * (pz - K.A[j][1]) - nz * (px - K.A[j][0])); });
+}
+template <class T, class S, bool PAIR>
+REX_HD void list_store_self(const SelfRows<T, S>& R, const SlotMem<T, S, PAIR>& L) {
+  using LM = SlotMem<T, S, PAIR>;
+  if constexpr (S::NSELF > 0) static_for<0, LM::NSROW>([&](auto RR) { constexpr int r = RR;
+    T* q = L.srow(r);
+    q[LM::soff(SR_PX)] = R.px[r]; q[LM::soff(SR_PZ)] = R.pz[r]; q[LM::soff(SR_NX)] = R.nx[r]; q[LM::soff(SR_NZ)] = R.nz[r];
+    q[LM::soff(SR_D)] = R.D[r]; q[LM::soff(SR_AREF)] = R.aref[r]; });
+}
+// slot_rows' results (registers, compile-time indices) into the column; friction per unit
+template <class T, class S, bool PAIR>
+REX_HD void list_store(const Constraints<T, S>& C, const LaneParams<T, S>& P, const SlotMem<T, S, PAIR>& L) {
+  using LM = SlotMem<T, S, PAIR>;
+  static_for<0, LM::NUNIT>([&](auto UU) { constexpr int u = UU; constexpr int k = PAIR ? 2 * u : u; constexpr int g = PAIR ? u : u / 2;
+    T* q = L.unit(u);
+    q[LM::off(SF_PX)] = C.px[k]; q[LM::off(SF_PZ)] = C.pz[k]; q[LM::off(SF_D)] = C.D[k]; q[LM::off(SF_AN)] = C.an[k]; q[LM::off(SF_AT)] = C.at[k];
+    q[LM::off(SF_MU)] = P.mu[g]; });
+}
+template <class T, class S, bool SELF, bool PAIR, int MAXIT = 24>
+REX_HD SolveStats solve_newton_list(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth)[S::NV], const T (&qacc_smooth)[S::NV],
+                                    const Kin<T, S>& K, const Constraints<T, S>& C, unsigned self_mask, const SlotMem<T, S, PAIR>& L,
+                                    T (&qacc)[S::NV], bool warm, bool have_a0, int ls_max, int ls_free, int corr) {
+  // self_mask: this lane's capsule-capsule rows (their data is in the column: list_store_self); replicated in both lanes of a pair
+  using LM = SlotMem<T, S, PAIR>;
+  constexpr int NU_ = LM::NUNIT;
+  struct { unsigned mask; } R{SELF ? self_mask : 0u};
+  unsigned ums = 0u;   // the capsule-capsule rows some lane of the wave has (wave-uniform)
+  if constexpr (SELF && S::NSELF > 0) {
+    static_for<0, LM::NSROW>([&](auto RR) { constexpr int r = RR; ums |= REX_WAVE_ANY(((R.mask >> r) & 1u) != 0u) ? (1u << r) : 0u; });
+#if defined(__HIP_DEVICE_COMPILE__)
+    ums = __builtin_amdgcn_readfirstlane(ums);
+#endif
+  }
+  const unsigned par = PAIR ? pair_parity() : 0u;
+  auto bit_of = [&](unsigned u) { return PAIR ? 2u * u + par : u; };   // slot bit (in con_mask / the edge sets) of unit u in THIS lane
+  auto anc_of = [&](unsigned u) { return anc_of_geom<S>(PAIR ? u : u >> 1); };
+  const bool has_rows = C.any || (SELF && R.mask != 0u);
+  static_for<0, S::NV>([&](auto II) { T prev = qacc[II], cold = qacc_smooth[II]; opaque(prev); opaque(cold);
+                                      qacc[II] = have_a0 ? ((warm && has_rows) ? prev : cold) : prev; });
+  SolveStats st{0, false, 0};
+  const T tol2 = sizeof(T) == 4 ? T(1e-9) : T(1e-24);
+  const T stag = sizeof(T) == 4 ? T(1e-6) : T(1e-15);
+  unsigned p_lim = ~0u, p_e1 = ~0u, p_e2 = ~0u, p_e3 = ~0u, p_self = ~0u;
+  bool lane_done = !has_rows && have_a0;
+  // the list: units some lane of the wave has inside the margin (wave-uniform; on the device a scalar register)
+  unsigned um = 0u;
+  static_for<0, NU_>([&](auto UU) { constexpr int u = UU; constexpr int k = PAIR ? 2 * u : u;
+    um |= REX_WAVE_ANY(((C.con_mask >> k) & (PAIR ? 3u : 1u)) != 0u) ? (1u << u) : 0u; });
+#if defined(__HIP_DEVICE_COMPILE__)
+  um = __builtin_amdgcn_readfirstlane(um);
+#endif
+  T Ma[S::NV];
+  sym_matvec<T, S>(M, qacc, Ma);
+  bool ma_dirty = false;
+  for (int it = 0; it < MAXIT; ++it) {
+    if (!REX_WAVE_ANY(!lane_done)) break;
+    if (ma_dirty) { sym_matvec<T, S>(M, qacc, Ma); ma_dirty = false; }
+    REX_COUNT(pass1, 1);
+    // ---- gradient, active edges and the Hessian's unit blocks in ONE walk over the list --------------------------------------------------------
+    // (the Hessian block of a unit needs only that unit's own active edges; a solve whose last walk finds every lane converged built its
+    // blocks for nothing, which is rare here: solves end on an exact step or an accepted correction)
+    T g[S::NV];
+    T fref = T(0);
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] = Ma[i] - qfrc_smooth[i]; fref += Ma[i] * Ma[i] + qfrc_smooth[i] * qfrc_smooth[i]; });
+    unsigned lim_on = 0, e1 = 0, e2 = 0, e3 = 0, self_on = 0;
+    static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+      if constexpr (S::limited[j]) {
+        T jar = C.lsig[j] * qacc[j + 2] - C.laref[j];
+        bool on = ((C.lim_mask >> j) & 1u) && jar < T(0);
+        if (on) lim_on |= 1u << j;
+        g[j + 2] += on ? C.lsig[j] * C.lD[j] * jar : T(0); } });
+    T Hs[S::NV][S::NV];   // this lane's unit blocks (PAIR: summed over the pair below)
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) Hs[i][j] = T(0); }); });
+    T Hself[(SELF && S::NSELF > 0) ? S::NV : 1][(SELF && S::NSELF > 0) ? S::NV : 1];   // capsule-capsule rows' terms (replicated: NOT summed over the pair)
+    if constexpr (SELF && S::NSELF > 0) static_for<2, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<2, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) Hself[i][j] = T(0); }); });
+    {
+      T gs[S::NV];
+      static_for<0, S::NV>([&](auto II) { gs[II] = T(0); });
+      for (unsigned m = um; m; m &= m - 1u) {
+        const unsigned u = (unsigned)__builtin_ctz(m);
+        T* q = L.unit(u);
+        const T px = q[LM::off(SF_PX)], pz = q[LM::off(SF_PZ)], D = q[LM::off(SF_D)], an = q[LM::off(SF_AN)], at = q[LM::off(SF_AT)], mu = q[LM::off(SF_MU)];
+        const unsigned b = bit_of(u), anc = anc_of(u);
+        const bool act = (C.con_mask >> b) & 1u;
+        on_path<S>(anc, [&](auto PC) { constexpr unsigned SUB = unsigned(int(PC));
+          T jt[S::NB], jn[S::NB];
+          list_jac<T, S, SUB>(K, px, pz, anc, jt, jn);
+          T t, n; list_dot<T, S, SUB>(jt, jn, qacc, t, n);
+          q[LM::off(SF_LT)] = t; q[LM::off(SF_LN)] = n;                 // J qacc: read again by the line-search walk
+          const T r1 = n + mu * t - (an + at), r2 = n - mu * t - (an - at), r3 = n - an;
+          const bool s1 = act && r1 < T(0), s2 = act && r2 < T(0), s3 = act && r3 < T(0);
+          e1 |= s1 ? (1u << b) : 0u; e2 |= s2 ? (1u << b) : 0u; e3 |= s3 ? (1u << b) : 0u;
+          const T f1 = s1 ? -D * r1 : T(0), f2 = s2 ? -D * r2 : T(0), f3 = s3 ? -D * r3 : T(0);
+          list_accum<T, S, SUB>(jt, jn, -(mu * (f1 - f2)), -(f1 + f2 + T(2) * f3), gs);
+          const T c1 = s1 ? D : T(0), c2 = s2 ? D : T(0), c3 = s3 ? D : T(0);
+          list_hess<T, S, SUB>(jt, jn, mu * mu * (c1 + c2), mu * (c1 - c2), c1 + c2 + T(2) * c3, Hs); });
+      }
+      if constexpr (PAIR) {
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] += gs[i] + pair_xchg(gs[i]); });
+        e1 |= pair_xchg(e1); e2 |= pair_xchg(e2); e3 |= pair_xchg(e3);
+      } else static_for<0, S::NV>([&](auto II) { constexpr int i = II; g[i] += gs[i]; });
+    }
+    if constexpr (SELF && S::NSELF > 0) {   // capsule-capsule rows: gradient and (rank-1) Hessian terms, replicated in both lanes of a pair
+      for (unsigned m = ums; m; m &= m - 1u) {
+        const unsigned r = (unsigned)__builtin_ctz(m);
+        T* q = L.srow(r);
+        T row[S::NB];
+        self_row<T, S>(K, q[LM::soff(SR_PX)], q[LM::soff(SR_PZ)], q[LM::soff(SR_NX)], q[LM::soff(SR_NZ)], r, row);
+        const T D = q[LM::soff(SR_D)];
+        T jq = T(0);
+        static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; jq += row[j] * qacc[j + 2]; });
+        q[LM::soff(SR_JQ)] = jq;
+        const T jar = jq - q[LM::soff(SR_AREF)];
+        const bool on = ((R.mask >> r) & 1u) && jar < T(0);
+        self_on |= on ? (1u << r) : 0u;
+        const T w = on ? D * jar : T(0), d = on ? D : T(0);
+        static_for<0, S::NB>([&](auto AA) { constexpr int a = AA;
+          g[a + 2] += row[a] * w;
+          static_for<0, a + 1>([&](auto BB) { constexpr int bq = BB;
+            if constexpr (dof_coupled<S>(a + 2, bq + 2)) Hself[a + 2][bq + 2] += d * row[a] * row[bq]; }); });
+      }
+    }
+    T gn = T(0);
+    static_for<0, S::NV>([&](auto II) { gn += g[II] * g[II]; });
+    const bool same_set = lim_on == p_lim && e1 == p_e1 && e2 == p_e2 && e3 == p_e3 && self_on == p_self;
+    p_lim = lim_on; p_e1 = e1; p_e2 = e2; p_e3 = e3; p_self = self_on;
+    lane_done = lane_done || same_set || !(gn > tol2 * fref);   // NaN counts as done
+    if (!REX_WAVE_ANY(!lane_done)) break;
+    REX_COUNT(pass2, 1);
+    // ---- Hessian of the current active set, Newton direction ----------------------------------------------------------------------------------
+    T H[S::NV][S::NV];
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<0, i + 1>([&](auto JJ) { constexpr int j = JJ;
+        if constexpr (dof_coupled<S>(i, j)) { if constexpr (PAIR) H[i][j] = M[i][j] + (Hs[i][j] + pair_xchg(Hs[i][j])); else H[i][j] = M[i][j] + Hs[i][j]; } }); });
+    static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+      if constexpr (S::limited[j]) H[j + 2][j + 2] += ((lim_on >> j) & 1u) ? C.lD[j] : T(0); });
+    if constexpr (SELF && S::NSELF > 0) static_for<2, S::NV>([&](auto II) { constexpr int i = II;
+      static_for<2, i + 1>([&](auto JJ) { constexpr int j = JJ; if constexpr (dof_coupled<S>(i, j)) H[i][j] += Hself[i][j]; }); });
+    ldl_factor<T, S>(H);
+    T sr[S::NV];
+    static_for<0, S::NV>([&](auto II) { sr[II] = -g[II]; });
+    ldl_solve<T, S>(H, sr);
+    if constexpr (SELF && S::NSELF > 0) {   // J sr of the capsule-capsule rows into the column
+      for (unsigned m = ums; m; m &= m - 1u) {
+        const unsigned r = (unsigned)__builtin_ctz(m);
+        T* q = L.srow(r);
+        T row[S::NB];
+        self_row<T, S>(K, q[LM::soff(SR_PX)], q[LM::soff(SR_PZ)], q[LM::soff(SR_NX)], q[LM::soff(SR_NZ)], r, row);
+        T jv = T(0);
+        static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; jv += row[j] * sr[j + 2]; });
+        q[LM::soff(SR_JV)] = jv;
+      }
+    }
+    // ---- line search on phi(alpha): J sr of every listed unit into the column and phi'(1) in the same walk ------------------------------------
+    T Ms[S::NV];
+    sym_matvec<T, S>(M, sr, Ms);
+    T q1 = T(0), q2 = T(0), d0 = T(0);
+    static_for<0, S::NV>([&](auto II) { q1 += sr[II] * (Ma[II] - qfrc_smooth[II]); q2 += sr[II] * Ms[II]; d0 += sr[II] * g[II]; });
+    unsigned m_lim, m_e1, m_e2, m_e3, m_self;
+    // phi'(a), phi''(a) without the units' part, and the limit / self rows active at a
+    auto deriv_head = [&](T a, T& d1, T& d2) {
+      REX_COUNT(ls_evals, 1);
+      m_lim = m_e1 = m_e2 = m_e3 = m_self = 0u;
+      d1 = q1 + a * q2; d2 = q2;
+      static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+        if constexpr (S::limited[j]) {
+          T lr = C.lsig[j] * qacc[j + 2] - C.laref[j], lv = C.lsig[j] * sr[j + 2];
+          T x = lr + a * lv; bool on = ((C.lim_mask >> j) & 1u) && x < T(0);
+          if (on) m_lim |= 1u << j;
+          T dd = on ? C.lD[j] : T(0); d1 += dd * x * lv; d2 += dd * lv * lv; } });
+      if constexpr (SELF && S::NSELF > 0) {
+        for (unsigned m = ums; m; m &= m - 1u) {
+          const unsigned r = (unsigned)__builtin_ctz(m);
+          const T* q = L.srow(r);
+          const T vv = q[LM::soff(SR_JV)], x = q[LM::soff(SR_JQ)] - q[LM::soff(SR_AREF)] + a * vv;
+          const bool on = ((R.mask >> r) & 1u) && x < T(0);
+          m_self |= on ? (1u << r) : 0u;
+          const T dd = on ? q[LM::soff(SR_D)] : T(0);
+          d1 += dd * x * vv; d2 += dd * vv * vv;
+        }
+      }
+    };
+    // one unit's part of phi', phi'' and of the sets at a, from (J qacc, J sr)
+    auto deriv_unit = [&](T a, unsigned b, bool act, T D, T an, T at, T mu, T jt, T jn, T vt, T vn, T& d1s, T& d2s) {
+      const T r0 = jn + mu * jt - (an + at), r1 = jn - mu * jt - (an - at), r2 = jn - an;
+      const T v0 = vn + mu * vt, v1 = vn - mu * vt, v2 = vn;
+      const T x0 = r0 + a * v0, x1 = r1 + a * v1, x2 = r2 + a * v2;
+      const bool o0 = act && x0 < T(0), o1 = act && x1 < T(0), o2 = act && x2 < T(0);
+      m_e1 |= o0 ? (1u << b) : 0u; m_e2 |= o1 ? (1u << b) : 0u; m_e3 |= o2 ? (1u << b) : 0u;
+      const T w0 = o0 ? D : T(0), w1 = o1 ? D : T(0), w2 = o2 ? T(2) * D : T(0);
+      d1s += w0 * x0 * v0 + w1 * x1 * v1 + w2 * x2 * v2; d2s += w0 * v0 * v0 + w1 * v1 * v1 + w2 * v2 * v2;
+    };
+    auto deriv_tail = [&](T& d1, T& d2, T d1s, T d2s) {
+      if constexpr (PAIR) {
+        d1 += d1s + pair_xchg(d1s); d2 += d2s + pair_xchg(d2s);
+        m_e1 |= pair_xchg(m_e1); m_e2 |= pair_xchg(m_e2); m_e3 |= pair_xchg(m_e3);
+      } else { d1 += d1s; d2 += d2s; }
+    };
+    const T d1ref = abs_t(d0) * T(sizeof(T) == 4 ? 1e-5 : 1e-13) + T(1e-30);
+    T a = T(1), lo = T(0), hi = T(-1), d1, d2;
+    {
+      deriv_head(a, d1, d2);
+      T d1s = T(0), d2s = T(0);
+      for (unsigned m = um; m; m &= m - 1u) {
+        const unsigned u = (unsigned)__builtin_ctz(m);
+        T* q = L.unit(u);
+        const T px = q[LM::off(SF_PX)], pz = q[LM::off(SF_PZ)], D = q[LM::off(SF_D)], an = q[LM::off(SF_AN)], at = q[LM::off(SF_AT)], mu = q[LM::off(SF_MU)];
+        const T t = q[LM::off(SF_LT)], n = q[LM::off(SF_LN)];
+        const unsigned b = bit_of(u), anc = anc_of(u);
+        const bool act = (C.con_mask >> b) & 1u;
+        on_path<S>(anc, [&](auto PC) { constexpr unsigned SUB = unsigned(int(PC));
+          T jt[S::NB], jn[S::NB];
+          list_jac<T, S, SUB>(K, px, pz, anc, jt, jn);
+          T vt, vn; list_dot<T, S, SUB>(jt, jn, sr, vt, vn);
+          q[LM::off(SF_LVT)] = vt; q[LM::off(SF_LVN)] = vn;
+          deriv_unit(a, b, act, D, an, at, mu, t, n, vt, vn, d1s, d2s); });
+      }
+      deriv_tail(d1, d2, d1s, d2s);
+    }
+    auto deriv = [&](T aa, T& dd1, T& dd2) {   // phi' at another alpha: everything it needs is in the column
+      deriv_head(aa, dd1, dd2);
+      T d1s = T(0), d2s = T(0);
+      for (unsigned m = um; m; m &= m - 1u) {
+        const unsigned u = (unsigned)__builtin_ctz(m);
+        const T* q = L.unit(u);
+        const unsigned b = bit_of(u);
+        deriv_unit(aa, b, (C.con_mask >> b) & 1u, q[LM::off(SF_D)], q[LM::off(SF_AN)], q[LM::off(SF_AT)], q[LM::off(SF_MU)],
+                   q[LM::off(SF_LT)], q[LM::off(SF_LN)], q[LM::off(SF_LVT)], q[LM::off(SF_LVN)], d1s, d2s);
+      }
+      deriv_tail(dd1, dd2, d1s, d2s);
+    };
+    bool ls_done = lane_done || abs_t(d1) <= d1ref;
+    const int ls_cap = it < ls_free ? 0 : ls_max;
+    for (int ls = 0; ls < ls_cap; ++ls) {
+      if (!REX_WAVE_ANY(!ls_done)) break;
+      if (d1 < T(0)) lo = a; else hi = a;
+      T an_ = a - d1 * rcp_t(d2);
+      if (hi >= T(0) && (an_ <= lo || an_ >= hi)) an_ = T(0.5) * (lo + hi);
+      an_ = max_t(an_, lo);
+      T prev = a;
+      a = ls_done ? a : an_;
+      deriv(a, d1, d2);
+      ls_done = ls_done || abs_t(d1) <= d1ref || a == prev;
+    }
+    const bool exact_step = a == T(1) && m_lim == lim_on && m_e1 == e1 && m_e2 == e2 && m_e3 == e3 && m_self == self_on;
+    a = lane_done ? T(0) : a;
+    T amax = T(0), smax = T(0);
+    static_for<0, S::NV>([&](auto II) { qacc[II] += a * sr[II]; Ma[II] += a * Ms[II]; amax = max_t(amax, abs_t(qacc[II])); smax = max_t(smax, abs_t(a * sr[II])); });
+    lane_done = lane_done || exact_step || smax <= stag * (T(1) + amax);
+    // ---- one-group correction (see solve_newton): one joint limit or the edges of ONE unit toggled along a full step ----------------------
+    {
+      const unsigned t_lim = lim_on ^ m_lim, t1 = e1 ^ m_e1, t2 = e2 ^ m_e2, t3 = e3 ^ m_e3, tm = t1 | t2 | t3;
+      const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
+      bool can = !lane_done && a == T(1) && corr != 0 && m_self == self_on && ((nl == 1 && ns == 0) || (nl == 0 && ns == 1));
+      if (REX_WAVE_ANY(can)) {
+        T Ut[S::NV], Un[S::NV], Ctt = T(0), Ctn = T(0), Cnn = T(0), wt = T(0), wn = T(0);
+        static_for<0, S::NV>([&](auto II) { Ut[II] = T(0); Un[II] = T(0); });
+        const bool lim_lane = !PAIR || par == 0u;   // the limit group is replicated: only one lane of a pair may add it
+        static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+          if constexpr (S::limited[j]) {
+            const bool b = ((t_lim >> j) & 1u) && lim_lane && can;
+            const T sg = ((m_lim >> j) & 1u) ? T(1) : T(-1);
+            const T xr = C.lsig[j] * qacc[j + 2] - C.laref[j];
+            Ut[j + 2] = b ? C.lsig[j] : T(0); Ctt += b ? sg * C.lD[j] : T(0); wt += b ? sg * C.lD[j] * xr : T(0); } });
+        {   // the toggled unit: a per-lane index into the column (lanes without one read unit 0 and contribute nothing)
+          const unsigned kb = ns == 1 ? (unsigned)__builtin_ctz(tm | 0x80000000u) : 0u;          // slot bit
+          const bool mine = can && ns == 1 && (!PAIR || (kb & 1u) == par);
+          const unsigned u = mine ? (PAIR ? kb >> 1 : kb) : 0u;
+          const T* q = L.unit(u);
+          const T px = q[LM::off(SF_PX)], pz = q[LM::off(SF_PZ)], Dk = q[LM::off(SF_D)], an = q[LM::off(SF_AN)], at = q[LM::off(SF_AT)], mu = q[LM::off(SF_MU)];
+          // (lanes without a toggled unit read unit 0, whose J qacc / J sr words were never written if it is not on the list: select, do not
+          // multiply by zero -- 0 * garbage is NaN)
+          const T jt1 = mine ? q[LM::off(SF_LT)] + q[LM::off(SF_LVT)] : T(0), jn1 = mine ? q[LM::off(SF_LN)] + q[LM::off(SF_LVN)] : T(0);   // J x1 (alpha = 1)
+          T jt[S::NB], jn[S::NB];
+          list_jac<T, S, (1u << S::NB) - 1u>(K, px, pz, anc_of(u), jt, jn);   // (per-lane unit: every body, per-lane weights)
+          const T x0 = jn1 + mu * jt1 - (an + at), x1 = jn1 - mu * jt1 - (an - at), x2 = jn1 - an;
+          const T d1_ = T(int((m_e1 >> kb) & 1u) - int((e1 >> kb) & 1u)), d2_ = T(int((m_e2 >> kb) & 1u) - int((e2 >> kb) & 1u)),
+                  d3_ = T(int((m_e3 >> kb) & 1u) - int((e3 >> kb) & 1u));
+          const T on = mine ? T(1) : T(0), Dm = mine ? Dk : T(0);
+          Ctt += Dm * mu * mu * (d1_ + d2_); Ctn += Dm * mu * (d1_ - d2_); Cnn += Dm * (d1_ + d2_ + T(2) * d3_);
+          wt += Dm * mu * (d1_ * x0 - d2_ * x1); wn += Dm * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
+          list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, on, T(0), Ut); list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, T(0), on, Un);
+        }
+        T vt[S::NV], vn[S::NV];
+        static_for<0, S::NV>([&](auto II) { vt[II] = Ut[II]; vn[II] = Un[II]; });
+        ldl_solve<T, S>(H, vt); ldl_solve<T, S>(H, vn);
+        T Gtt = T(0), Gtn = T(0), Gnn = T(0);
+        static_for<0, S::NV>([&](auto II) { Gtt += Ut[II] * vt[II]; Gtn += Ut[II] * vn[II]; Gnn += Un[II] * vn[II]; });
+        const T a11 = T(1) + Ctt * Gtt + Ctn * Gtn, a12 = Ctt * Gtn + Ctn * Gnn, a21 = Ctn * Gtt + Cnn * Gtn, a22 = T(1) + Ctn * Gtn + Cnn * Gnn;
+        const T det = a11 * a22 - a12 * a21;
+        bool good = det > T(1e-3);
+        if constexpr (PAIR) good = good && (pair_xchg(good ? 1u : 0u) != 0u);
+        can = can && good;
+        const T idet = can ? rcp_t(det) : T(0);
+        const T zt = can ? (a22 * wt - a12 * wn) * idet : T(0), zn = can ? (a11 * wn - a21 * wt) * idet : T(0);
+        T dx[S::NV];
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = zt * vt[i] + zn * vn[i];
+          if constexpr (PAIR) dx[i] += pair_xchg(dx[i]);
+          qacc[i] -= dx[i]; });
+        // the set at x2
+        unsigned v_lim = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
+        static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+          if constexpr (S::limited[j]) { const T x = C.lsig[j] * qacc[j + 2] - C.laref[j]; if (((C.lim_mask >> j) & 1u) && x < T(0)) v_lim |= 1u << j; } });
+        for (unsigned m = um; m; m &= m - 1u) {
+          const unsigned u = (unsigned)__builtin_ctz(m);
+          const T* q = L.unit(u);
+          const T px = q[LM::off(SF_PX)], pz = q[LM::off(SF_PZ)], an = q[LM::off(SF_AN)], at = q[LM::off(SF_AT)], mu = q[LM::off(SF_MU)];
+          const T jt1 = q[LM::off(SF_LT)] + q[LM::off(SF_LVT)], jn1 = q[LM::off(SF_LN)] + q[LM::off(SF_LVN)];
+          const unsigned b = bit_of(u), anc = anc_of(u);
+          const bool act = (C.con_mask >> b) & 1u;
+          on_path<S>(anc, [&](auto PC) { constexpr unsigned SUB = unsigned(int(PC));
+            T jt[S::NB], jn[S::NB];
+            list_jac<T, S, SUB>(K, px, pz, anc, jt, jn);
+            T ut, un; list_dot<T, S, SUB>(jt, jn, dx, ut, un);
+            const T jt2 = jt1 - ut, jn2 = jn1 - un;
+            const T x0 = jn2 + mu * jt2 - (an + at), x1 = jn2 - mu * jt2 - (an - at), x2 = jn2 - an;
+            v1 |= (act && x0 < T(0)) ? (1u << b) : 0u; v2 |= (act && x1 < T(0)) ? (1u << b) : 0u; v3 |= (act && x2 < T(0)) ? (1u << b) : 0u; });
+        }
+        if constexpr (PAIR) { v1 |= pair_xchg(v1); v2 |= pair_xchg(v2); v3 |= pair_xchg(v3); }
+        bool ok2 = v_lim == m_lim && v1 == m_e1 && v2 == m_e2 && v3 == m_e3;
+        if constexpr (SELF && S::NSELF > 0) {   // a lane with self rows: they must stay as they were at x1 (their toggles are not part of the group)
+          for (unsigned m = ums; m; m &= m - 1u) {
+            const unsigned r = (unsigned)__builtin_ctz(m);
+            const T* q = L.srow(r);
+            T row[S::NB];
+            self_row<T, S>(K, q[LM::soff(SR_PX)], q[LM::soff(SR_PZ)], q[LM::soff(SR_NX)], q[LM::soff(SR_NZ)], r, row);
+            T jar = -q[LM::soff(SR_AREF)];
+            static_for<0, S::NB>([&](auto JJ) { constexpr int j = JJ; jar += row[j] * qacc[j + 2]; });
+            ok2 = ok2 && ((((R.mask >> r) & 1u) && jar < T(0)) == (((m_self >> r) & 1u) != 0u));
+          }
+        }
+        lane_done = lane_done || (can && ok2);
+        p_lim = can ? m_lim : p_lim; p_e1 = can ? m_e1 : p_e1; p_e2 = can ? m_e2 : p_e2; p_e3 = can ? m_e3 : p_e3; p_self = can ? m_self : p_self;
+        ma_dirty = true;
+        REX_COUNT(nocon, 1);
+      }
+    }
+    st.iters = it + 1;
+    if (it == MAXIT - 1) st.capped = REX_WAVE_ANY(!lane_done);
+  }
+  return st;
+}
+
 #if defined(REX_KTIME) && defined(__HIP_DEVICE_COMPILE__)
 // diagnostic build only: per-phase cycle stamps (s_memtime), summed per wave into g_ktime[]
 extern __device__ unsigned long long g_ktime[24 + 72];
@@ -1129,10 +1583,13 @@ extern __device__ unsigned long long g_ktime[24 + 72];
 #endif
 
 // one forward-dynamics evaluation: qacc(q, v, ctrl)  ([3P] mj_forward)
-template <class T, class S, bool PAIR = false, bool ROLLED = false>
+// GEN: which code the general solver modes (1, 2) run -- 0 the unrolled per-slot instantiations, 1 the rolled ROW-list solver (the hopper's
+// 256-register two-waves-per-SIMD kernel), 2 the LIST solver (per-unit data in `slot_mem`, this lane's column: LDS on the device)
+template <class T, class S, bool PAIR = false, int GEN = 0>
 REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
                           const LaneParams<T, S>& P, const SolParams<T>& sp, T (&qacc)[S::NV], T (&M)[S::NV][S::NV],
-                          bool warm = false) {
+                          bool warm = false, T* slot_mem = nullptr) {
+  constexpr bool ROLLED = GEN == 1;
   REX_STAMP(t_0);
   REX_MARK("kinematics");
   REX_PSTAMP(p_0, q[0]);
@@ -1215,6 +1672,24 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
       slot_rows<T, S, FAST, false>(v, G, P, sp, K, C);
       st = solve_newton<T, S, false, FAST, false>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr);
     }
+  }
+#if defined(REX_DIAG_NOGENERAL)   // timing diagnostics only (WRONG results for waves that leave the feet-only path): what the general instantiations cost the kernel by being in it
+  else if (mode == 1 || mode == 2) static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+#else
+  else if (GEN == 2 && (mode == 1 || mode == 2)) {   // the LIST solver: one instantiation for both modes (a lane without self rows has R.mask == 0)
+    if constexpr (GEN == 2) {
+      constexpr unsigned UNITS = PAIR ? (ALL & 0x55555555u) : ALL;   // PAIR: the even slot 2 g holds the lane's own end (detect_constraints<PAIR>)
+      slot_rows<T, S, UNITS, true, PAIR>(v, G, P, sp, K, C);
+      SlotMem<T, S, PAIR> L;
+#if defined(__HIP_DEVICE_COMPILE__)
+      L.p = slot_mem;
+#else
+      T host_col[SlotMem<T, S, PAIR>::WORDS]; L.p = slot_mem ? slot_mem : host_col;
+#endif
+      list_store<T, S, PAIR>(C, P, L);
+      if (mode == 2) list_store_self<T, S, PAIR>(R, L);   // (mode 1: R.mask == 0 in every lane, nothing of R is read)
+      st = solve_newton_list<T, S, (S::NSELF > 0), PAIR>(M, f, a0, K, C, R.mask, L, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr);
+    }
   } else if (ROLLED && (mode == 1 || mode == 2)) {   // (one call site for both: the row list carries the self rows when there are any)
     if constexpr (ROLLED) {
       if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
@@ -1225,14 +1700,16 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
     }
   } else if (mode == 2) {
     if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);   // the general instantiations run replicated in both lanes of a pair: every slot
-    if constexpr (S::NSELF > 0 && !ROLLED) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr); }
+    if constexpr (S::NSELF > 0 && GEN == 0) { slot_rows<T, S, ALL, true>(v, G, P, sp, K, C); st = solve_newton<T, S, true, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr); }
   } else if (mode == 1) {
-    if constexpr (!ROLLED) {
+    if constexpr (GEN == 0) {
       if constexpr (PAIR) detect_constraints<T, S, false>(q, v, G, sp, K, C);
       slot_rows<T, S, ALL, true>(v, G, P, sp, K, C);
       st = solve_newton<T, S, false, ALL, true>(M, f, a0, K, C, R, P, qacc, warm, have_a0, sp.ls_max, sp.ls_free, sp.corr);
     }
-  } else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
+  }
+#endif
+  else static_for<0, S::NV>([&](auto II) { qacc[II] = a0[II]; });
 #if defined(REX_KSTATS) && defined(__HIP_DEVICE_COMPILE__)
   if (mode == 3 && (threadIdx.x & 63) == 0) atomicAdd(&g_kstats[7], 1ull);   // wave-solves on the fast path
 #endif
@@ -1256,9 +1733,9 @@ REX_HD SolveStats forward(const T (&q)[S::NV], const T (&v)[S::NV], const T (&ct
 
 // one mj_step: RK4 ([3P] mj_RungeKutta, N=4) or semi-implicit Euler with implicit joint damping
 // ([3P] mj_Euler).  Returns the OR of "solver hit its cap".
-template <class T, class S, bool PAIR = false, bool ROLLED = false>
+template <class T, class S, bool PAIR = false, int GEN = 0>
 REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const PlanarGeom<T, S>& G,
-                    const LaneParams<T, S>& P, const SolParams<T>& sp, T (&acc)[S::NV], bool warm) {
+                    const LaneParams<T, S>& P, const SolParams<T>& sp, T (&acc)[S::NV], bool warm, T* slot_mem = nullptr) {
   // acc: in = qacc of the previous evaluation (solver warm start when `warm`), out = qacc of the last one
   const T h = T(S::TIMESTEP);
   T M[S::NV][S::NV];
@@ -1270,7 +1747,7 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
     static_for<0, S::NV>([&](auto II) { q0[II] = q[II]; v0[II] = v[II]; dq[II] = T(0); dv[II] = T(0); });
 #pragma unroll 1
     for (int stage = 0; stage < 4; ++stage) {
-      capped |= forward<T, S, PAIR, ROLLED>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0)).capped;
+      capped |= forward<T, S, PAIR, GEN>(q, v, ctrl, G, P, sp, acc, M, sp.warm && (warm || stage > 0), slot_mem).capped;
       const T w = (stage == 0 || stage == 3) ? T(1.0 / 6) : T(1.0 / 3);   // B = [1/6 1/3 1/3 1/6]
       const T c = stage == 2 ? h : T(0.5) * h;                             // A = [.5; 0 .5; 0 0 1]
       static_for<0, S::NV>([&](auto II) { constexpr int i = II;
@@ -1281,7 +1758,7 @@ REX_HD bool substep(T (&q)[S::NV], T (&v)[S::NV], const T (&ctrl)[S::NU], const 
     }
   } else {
     T rhs[S::NV];
-    capped |= forward<T, S, PAIR, ROLLED>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm).capped;
+    capped |= forward<T, S, PAIR, GEN>(q, v, ctrl, G, P, sp, acc, M, sp.warm && warm, slot_mem).capped;
     // (M + h*diag(damping)) a = qfrc_smooth + qfrc_constraint = M qacc
     sym_matvec<T, S>(M, acc, rhs);
     static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ; M[j + 2][j + 2] += h * G.damping[j]; });

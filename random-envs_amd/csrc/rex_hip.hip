@@ -354,8 +354,16 @@ planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
   bool capped = false;
   float acc[S::NV];
   static_for<0, S::NV>([&](auto KK) { acc[KK] = 0.0f; });
+  // which code the general solver modes run: the LIST solver in the two-lanes-per-env kernels (per-unit data in a column of LDS, one column per
+  // lane: 9 - 20 KB per wave), the rolled row list in the hopper's two-waves-per-SIMD kernel, the unrolled per-slot instantiations otherwise
+  constexpr int GEN = PAIR ? 2 : (ROLLED ? 1 : 0);
+  float* slot_col = nullptr;
+  if constexpr (GEN == 2) {
+    __shared__ float slot_lds[SlotMem<float, S, PAIR>::WORDS];
+    slot_col = slot_lds + threadIdx.x;
+  }
 #pragma unroll 1
-  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S, PAIR, ROLLED>(q, v, ctrl, G, P, sp, acc, f > 0);   // do_simulation, jinja_mujoco_env.py:170-173
+  for (int f = 0; f < S::FRAME_SKIP; f++) capped |= substep<float, S, PAIR, GEN>(q, v, ctrl, G, P, sp, acc, f > 0, slot_col);   // do_simulation, jinja_mujoco_env.py:170-173
   if (PAIR && (threadIdx.x & 1u)) return;   // the even lane of a pair writes the results and runs the fused reset
   // the output addresses are formed from an opaque copy of the lane index: formed from `i`, the compiler computes all of them
   // next to the loads at the top, carries them through the solver, spills them and reloads each with a wait of its own
@@ -1097,7 +1105,8 @@ static int create_body(rex_env* h, int env_kind, int variant, int64_t batch, int
   // step are a visible share of it (32 768 envs: + 10 % env-steps/s, 65 536: + 9 %, 131 072: + 4.5 %, 2^20: - 0.5 %)
   h->fused_derive = batch < 524288 ? 1 : 0;
   if (knob("REX_FUSED_DERIVE")) h->fused_derive = atoi(knob("REX_FUSED_DERIVE")) ? 1 : 0;
-  if (!h->sp.fast) h->pair = 0;   // the pair split lives in the feet-only instantiation
+  if (!h->sp.fast && !knob("REX_PAIR")) h->pair = 0;   // REX_FAST=0 is the strict-lane-independence mode: one lane per env unless REX_PAIR asks for the pair kernel
+                                                        // (whose general path is the list solver: REX_FAST=0 REX_PAIR=1 runs it on every lane)
   if (h->pair) h->rolled = 0;     // the two-waves-per-SIMD kernel is a one-lane-per-env one
   // xi <- nominal task, state <- qpos0
   HIP_TRY(hipMemcpy(h->d_scratch, h->nominal_xi, sizeof(float) * full.task_dim, hipMemcpyHostToDevice));
@@ -1523,7 +1532,6 @@ extern "C" int rex_set_launch_shape(rex_t* h, const int32_t* shape) {
   if (shape[2] > 0 && h->kind != REX_HOPPER) return set_err(REX_ERR_ARG, "rex_set_launch_shape: the rolled kernel exists for the hopper only");
   if (shape[3] > 0 && h->kind != REX_HUMANOID) return set_err(REX_ERR_ARG, "rex_set_launch_shape: hum_pair is a shape of the humanoid");
   if (pair && rolled) return set_err(REX_ERR_ARG, "rex_set_launch_shape: the rolled kernel is a one-lane-per-env kernel (pair and rolled exclude each other)");
-  if (pair && !h->sp.fast) return set_err(REX_ERR_STATE, "rex_set_launch_shape: the pair split lives in the feet-only solver instantiation, which REX_FAST=0 switched off");
   h->lanes = lanes; h->pair = pair; h->rolled = rolled; h->hum_pair = hum_pair;
   return REX_OK;
 }

@@ -13,7 +13,8 @@ static int g_ls_max = -1, g_ls_free = -1;   // overrides of SolParams::ls_max / 
 extern "C" void ph_set_ls(int ls_max, int ls_free) { g_ls_max = ls_max; g_ls_free = ls_free; }
 static int g_last_mode = -1;   // SolveStats::mode of the last ph_forward
 extern "C" void ph_set_fast(int f) { g_fast = f; }
-static int g_rolled = 0;   // 1 = the rolled general solver (the instantiation of the 256-register hopper kernel, planar_engine.hpp::solve_newton_rolled)
+static int g_rolled = 0;   // the GEN flag of forward(): 0 = unrolled general instantiations, 1 = the rolled ROW-list solver (the 256-register hopper kernel,
+                           // planar_engine.hpp::solve_newton_rolled), 2 = the LIST solver of the two-lanes-per-env kernels (solve_newton_list; one lane walks both ends here)
 extern "C" void ph_set_rolled(int r) { g_rolled = r; }
 extern "C" int ph_last_mode() { return g_last_mode; }
 
@@ -36,7 +37,8 @@ static void run_step(int n, int nsub, const double* qpos, const double* qvel, co
     LaneParams<T, S> P; lane_params(S{}, x, P);
     bool cap = false; T acc[S::NV];
     for (int k = 0; k < S::NV; k++) acc[k] = T(0);
-    for (int s = 0; s < nsub; s++) cap |= g_rolled ? substep<T, S, false, true>(q, v, c, G, P, sp, acc, s > 0) : substep<T, S>(q, v, c, G, P, sp, acc, s > 0);
+    for (int s = 0; s < nsub; s++) cap |= g_rolled == 2 ? substep<T, S, false, 2>(q, v, c, G, P, sp, acc, s > 0)
+                                            : (g_rolled ? substep<T, S, false, 1>(q, v, c, G, P, sp, acc, s > 0) : substep<T, S>(q, v, c, G, P, sp, acc, s > 0));
     for (int k = 0; k < S::NV; k++) { qpos_out[(size_t)k * n + i] = double(q[k]); qvel_out[(size_t)k * n + i] = double(v[k]); }
     if (capped) capped[i] = cap;
   }
@@ -56,7 +58,7 @@ static void run_forward(const double* qpos, const double* qvel, const double* ac
   sp.fast = g_fast; if (g_ls_max >= 0) sp.ls_max = g_ls_max; if (g_ls_free >= 0) sp.ls_free = g_ls_free;
   LaneParams<T, S> P; lane_params(S{}, x, P);
   for (int i = 0; i < S::NV; i++) for (int j = 0; j < S::NV; j++) M[i][j] = T(0);
-  SolveStats st = g_rolled ? forward<T, S, false, true>(q, v, c, G, P, sp, a, M) : forward<T, S>(q, v, c, G, P, sp, a, M);
+  SolveStats st = g_rolled == 2 ? forward<T, S, false, 2>(q, v, c, G, P, sp, a, M) : (g_rolled ? forward<T, S, false, 1>(q, v, c, G, P, sp, a, M) : forward<T, S>(q, v, c, G, P, sp, a, M));
   for (int k = 0; k < S::NV; k++) qacc[k] = double(a[k]);
   for (int i = 0; i < S::NV; i++) for (int j = 0; j < S::NV; j++) Mout[i * S::NV + j] = double(j <= i ? M[i][j] : M[j][i]);
   *iters = st.iters; g_last_mode = st.mode;

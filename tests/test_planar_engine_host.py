@@ -127,11 +127,14 @@ def test_fast_and_general_solver_instantiations_agree(kind):
     assert np.percentile(e32, 99) < 2e-4 and np.abs(q32f - q32g).max() < 2e-5
 
 
+@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("kind", KINDS)
-def test_rolled_general_solver_matches_the_unrolled_one_and_the_oracle(kind):
-    """solve_newton_rolled (the general path of the 256-register hopper kernel: runtime loops over a row list) is the same Newton method on
-    the same rows as the unrolled per-slot solver: same minimiser in fp64 (both against the oracle too), fp32 tolerance in fp32.  Run with the
-    feet-only path switched off so that EVERY evaluation goes through it, and on the self-collision states with it on."""
+def test_rolled_general_solver_matches_the_unrolled_one_and_the_oracle(kind, gen):
+    """solve_newton_rolled (gen 1: the general path of the 256-register hopper kernel, runtime loops over a ROW list) and solve_newton_list (gen 2:
+    the general path of the two-lanes-per-env kernels, runtime loops over the list of contact units with their data in a column of memory, one-group
+    correction included) are the same Newton method on the same rows as the unrolled per-slot solver: same minimiser in fp64 (both against the
+    oracle too), fp32 tolerance in fp32.  Run with the feet-only path switched off so that EVERY evaluation goes through it, and on the
+    self-collision states with it on."""
     d = DIMS[kind]
     q, v, xi = rollout_states(kind, 300, steps_max=50, seed=11)
     a = np.random.RandomState(5).uniform(-1, 1, (300, d["nu"]))
@@ -139,7 +142,7 @@ def test_rolled_general_solver_matches_the_unrolled_one_and_the_oracle(kind):
     try:
         set_fast(0)
         set_rolled(0); qu, vu, _ = host_step(kind, False, q, v, a, xi, d["frame_skip"])
-        set_rolled(1); qr, vr, cap = host_step(kind, False, q, v, a, xi, d["frame_skip"]); q32, v32, cap32 = host_step(kind, True, q, v, a, xi, d["frame_skip"])
+        set_rolled(gen); qr, vr, cap = host_step(kind, False, q, v, a, xi, d["frame_skip"]); q32, v32, cap32 = host_step(kind, True, q, v, a, xi, d["frame_skip"])
         set_fast(1); qf, vf, _ = host_step(kind, False, q, v, a, xi, d["frame_skip"])
         modes = set()
         for i in range(0, 300, 5):
@@ -159,11 +162,12 @@ def test_rolled_general_solver_matches_the_unrolled_one_and_the_oracle(kind):
     assert np.percentile(eq, 99) < 2e-5 and np.percentile(ev, 99) < 2e-4, (eq.max(), ev.max())
 
 
-def test_rolled_solver_on_hopper_self_collision_rows():
-    """the row list carries the capsule-capsule rows (mode 2) as well"""
+@pytest.mark.parametrize("gen", [1, 2])
+def test_rolled_solver_on_hopper_self_collision_rows(gen):
+    """the row list / the unit list carries the capsule-capsule rows (mode 2) as well"""
     xi = np.array(SPECS["hopper"].nominal_task); rng = np.random.RandomState(3); hits = 0
     try:
-        set_rolled(1)
+        set_rolled(gen)
         for _ in range(1500):
             q = np.array([0, rng.uniform(1.2, 1.6), rng.uniform(-.3, .3), rng.uniform(-2.6, -1.5), rng.uniform(-2.6, -1.5), rng.uniform(-.8, .8)])
             v = rng.uniform(-1, 1, 6); a = rng.uniform(-1, 1, 3)
