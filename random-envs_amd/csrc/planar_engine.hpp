@@ -609,6 +609,116 @@ enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4,
 #define REX_COUNT(field, n) ((void)0)
 #endif
 
+// ---- Woodbury correction after a full Newton step: shared pieces ---------------------------------------------------------------------------
+// x1 = x + sr minimises the quadratic model of the set A its Hessian H was built for.  If the set at x1 differs from A in a few GROUPS of rows
+// -- a joint limit (one column e_j), or the pyramid edges of one floor slot (all combinations of its two basis rows j_t, j_n) -- the new set's
+// Newton step from x1 needs no new factorisation:  H1 = H + U dC U^T,  grad_A1(x1) = U w  =>  x2 = x1 - V (I + dC G)^-1 w,  V = H^-1 U,  G = U^T V.
+// One group is a 2 x 2 system (round 2).  TWO groups, one per lane of a pair (round 4): each lane solves for its own group's columns only and the
+// coupling G_AB = U_A^T V_B is formed from the partner's V (DPP); block elimination of the partner's 2 x 2 block gives each lane its own z.  The
+// groups are dealt by capsule END (slot parity = lane parity; a limit goes to the lane without a slot, two limits one each), so every combination
+// of two groups except two slots of the same end is covered: limit + slot is 3/4 of what keeps the hopper's slowest waves iterating.
+template <class T, class S>
+struct CorrGroup { T Ut[S::NV], Un[S::NV]; T ctt, ctn, cnn, wt, wn; };   // columns (U_n = 0 for a limit), dC (symmetric 2 x 2), w
+// which toggled rows virtual lane `vp` (0 / 1) takes.  SPLIT: two lanes share the groups by parity; else one lane takes the (single) group.
+template <bool SPLIT>
+REX_HD bool corr_valid(unsigned t_lim, unsigned tm, int corr) {
+  const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
+  if (nl + ns == 1) return corr != 0;
+  if (!SPLIT || corr < 2 || nl + ns != 2) return false;
+  return __builtin_popcount(tm & 0x55555555u) <= 1 && __builtin_popcount(tm & 0xAAAAAAAAu) <= 1;
+}
+template <bool SPLIT>
+REX_HD void corr_assign(unsigned t_lim, unsigned tm, unsigned vp, unsigned& my_lim, unsigned& my_slots) {
+  if constexpr (!SPLIT) { my_lim = t_lim; my_slots = tm; }
+  else {
+    const unsigned even = tm & 0x55555555u, odd = tm & 0xAAAAAAAAu;
+    my_slots = vp ? odd : even;
+    const int nl = __builtin_popcount(t_lim);
+    const unsigned lane_for_one = (even != 0u && odd == 0u) ? 1u : 0u;          // a single limit: the lane without a slot (lane 0 if neither has one)
+    const unsigned lo = t_lim & (0u - t_lim), hi = t_lim & (t_lim - 1u);        // two limits: the lower one to lane 0
+    my_lim = nl == 1 ? (vp == lane_for_one ? t_lim : 0u) : (nl == 2 ? (vp ? hi : lo) : 0u);
+  }
+}
+// z of MY group in the coupled system  [I + Cm Gmm, Cm X; Ct X^T, I + Ct Gtt] [zm; zt] = [wm; wt]  (X = Um^T Vt): eliminate the partner's block
+template <class T>
+REX_HD bool corr_pair_solve(T cmtt, T cmtn, T cmnn, T gmtt, T gmtn, T gmnn, T wmt, T wmn,
+                            T c2tt, T c2tn, T c2nn, T g2tt, T g2tn, T g2nn, T w2t, T w2n,
+                            T xtt, T xtn, T xnt, T xnn, T& zt, T& zn) {
+  const T t11 = T(1) + c2tt * g2tt + c2tn * g2tn, t12 = c2tt * g2tn + c2tn * g2nn, t21 = c2tn * g2tt + c2nn * g2tn, t22 = T(1) + c2tn * g2tn + c2nn * g2nn;
+  const T dT = t11 * t22 - t12 * t21;
+  bool ok = dT > T(1e-3);
+  const T iT = ok ? rcp_t(dT) : T(0);
+  const T b11 = c2tt * xtt + c2tn * xtn, b12 = c2tt * xnt + c2tn * xnn, b21 = c2tn * xtt + c2nn * xtn, b22 = c2tn * xnt + c2nn * xnn;   // Ct X^T
+  const T y11 = (t22 * b11 - t12 * b21) * iT, y12 = (t22 * b12 - t12 * b22) * iT, y21 = (t11 * b21 - t21 * b11) * iT, y22 = (t11 * b22 - t21 * b12) * iT;
+  const T y1 = (t22 * w2t - t12 * w2n) * iT, y2 = (t11 * w2n - t21 * w2t) * iT;
+  const T c11 = cmtt * xtt + cmtn * xnt, c12 = cmtt * xtn + cmtn * xnn, c21 = cmtn * xtt + cmnn * xnt, c22 = cmtn * xtn + cmnn * xnn;   // Cm X
+  const T s11 = T(1) + cmtt * gmtt + cmtn * gmtn - (c11 * y11 + c12 * y21), s12 = cmtt * gmtn + cmtn * gmnn - (c11 * y12 + c12 * y22);
+  const T s21 = cmtn * gmtt + cmnn * gmtn - (c21 * y11 + c22 * y21), s22 = T(1) + cmtn * gmtn + cmnn * gmnn - (c21 * y12 + c22 * y22);
+  const T r1 = wmt - (c11 * y1 + c12 * y2), r2 = wmn - (c21 * y1 + c22 * y2);
+  const T dS = s11 * s22 - s12 * s21;
+  ok = ok && dS > T(1e-3);
+  const T iS = ok ? rcp_t(dS) : T(0);
+  zt = (s22 * r1 - s12 * r2) * iS; zn = (s11 * r2 - s21 * r1) * iS;
+  return ok;
+}
+// dx = V (I + dC G)^-1 w for the group(s) `build(vp, group)` describes (all-zero group: none).  MODE 0: one group in this lane (the one-lane
+// device kernels); 1: this lane's group + the pair partner's (DPP); 2: both virtual lanes in this lane (host builds: the same arithmetic
+// as mode 1, so the CPU tests hold the two-group algebra to the oracle).  `two` (wave-uniform): some lane has two groups, form the coupling.
+template <class T, class S, int MODE, class Build>
+REX_HD bool corr_step(const T (&H)[S::NV][S::NV], bool two, unsigned par, Build&& build, T (&dx)[S::NV]) {
+  constexpr int NG_ = MODE == 2 ? 2 : 1;
+  CorrGroup<T, S> g[NG_];
+  T vt[NG_][S::NV], vn[NG_][S::NV], Gtt[NG_], Gtn[NG_], Gnn[NG_];
+  static_for<0, NG_>([&](auto LL) { constexpr int l = LL;
+    build(MODE == 2 ? unsigned(l) : par, g[l]);
+    static_for<0, S::NV>([&](auto II) { vt[l][II] = g[l].Ut[II]; vn[l][II] = g[l].Un[II]; });
+    ldl_solve<T, S>(H, vt[l]); ldl_solve<T, S>(H, vn[l]);
+    Gtt[l] = Gtn[l] = Gnn[l] = T(0);
+    static_for<0, S::NV>([&](auto II) { Gtt[l] += g[l].Ut[II] * vt[l][II]; Gtn[l] += g[l].Ut[II] * vn[l][II]; Gnn[l] += g[l].Un[II] * vn[l][II]; }); });
+  bool good;
+  if constexpr (MODE == 0) {
+    const T a11 = T(1) + g[0].ctt * Gtt[0] + g[0].ctn * Gtn[0], a12 = g[0].ctt * Gtn[0] + g[0].ctn * Gnn[0];
+    const T a21 = g[0].ctn * Gtt[0] + g[0].cnn * Gtn[0], a22 = T(1) + g[0].ctn * Gtn[0] + g[0].cnn * Gnn[0];
+    const T det = a11 * a22 - a12 * a21;
+    good = det > T(1e-3);
+    const T idet = good ? rcp_t(det) : T(0);
+    const T zt = (a22 * g[0].wt - a12 * g[0].wn) * idet, zn = (a11 * g[0].wn - a21 * g[0].wt) * idet;
+    static_for<0, S::NV>([&](auto II) { dx[II] = zt * vt[0][II] + zn * vn[0][II]; });
+  } else if constexpr (MODE == 1) {
+    T zt, zn;
+    if (two) {   // (wave-uniform) some pair couples two groups: the partner's scalars and V, the coupling X = Um^T Vt, block elimination
+      const T c2tt = pair_xchg(g[0].ctt), c2tn = pair_xchg(g[0].ctn), c2nn = pair_xchg(g[0].cnn), w2t = pair_xchg(g[0].wt), w2n = pair_xchg(g[0].wn);
+      const T g2tt = pair_xchg(Gtt[0]), g2tn = pair_xchg(Gtn[0]), g2nn = pair_xchg(Gnn[0]);
+      T xtt = T(0), xtn = T(0), xnt = T(0), xnn = T(0);
+      static_for<0, S::NV>([&](auto II) { const T pt = pair_xchg(vt[0][II]), pn = pair_xchg(vn[0][II]);
+        xtt += g[0].Ut[II] * pt; xtn += g[0].Ut[II] * pn; xnt += g[0].Un[II] * pt; xnn += g[0].Un[II] * pn; });
+      good = corr_pair_solve(g[0].ctt, g[0].ctn, g[0].cnn, Gtt[0], Gtn[0], Gnn[0], g[0].wt, g[0].wn, c2tt, c2tn, c2nn, g2tt, g2tn, g2nn, w2t, w2n,
+                             xtt, xtn, xnt, xnn, zt, zn);
+    } else {     // every pair has one group at most: each lane's own 2 x 2 (the lane without a group solves the identity)
+      const T a11 = T(1) + g[0].ctt * Gtt[0] + g[0].ctn * Gtn[0], a12 = g[0].ctt * Gtn[0] + g[0].ctn * Gnn[0];
+      const T a21 = g[0].ctn * Gtt[0] + g[0].cnn * Gtn[0], a22 = T(1) + g[0].ctn * Gtn[0] + g[0].cnn * Gnn[0];
+      const T det = a11 * a22 - a12 * a21;
+      good = det > T(1e-3);
+      const T idet = good ? rcp_t(det) : T(0);
+      zt = (a22 * g[0].wt - a12 * g[0].wn) * idet; zn = (a11 * g[0].wn - a21 * g[0].wt) * idet;
+    }
+    good = good && (pair_xchg(good ? 1u : 0u) != 0u);
+    zt = good ? zt : T(0); zn = good ? zn : T(0);
+    static_for<0, S::NV>([&](auto II) { constexpr int i = II; const T d = zt * vt[0][i] + zn * vn[0][i]; dx[i] = d + pair_xchg(d); });
+  } else {
+    T xtt = T(0), xtn = T(0), xnt = T(0), xnn = T(0);   // X = U_0^T V_1
+    if (two) static_for<0, S::NV>([&](auto II) { xtt += g[0].Ut[II] * vt[1][II]; xtn += g[0].Ut[II] * vn[1][II]; xnt += g[0].Un[II] * vt[1][II]; xnn += g[0].Un[II] * vn[1][II]; });
+    T z0t, z0n, z1t, z1n;
+    const bool ok0 = corr_pair_solve(g[0].ctt, g[0].ctn, g[0].cnn, Gtt[0], Gtn[0], Gnn[0], g[0].wt, g[0].wn,
+                                     g[1].ctt, g[1].ctn, g[1].cnn, Gtt[1], Gtn[1], Gnn[1], g[1].wt, g[1].wn, xtt, xtn, xnt, xnn, z0t, z0n);
+    const bool ok1 = corr_pair_solve(g[1].ctt, g[1].ctn, g[1].cnn, Gtt[1], Gtn[1], Gnn[1], g[1].wt, g[1].wn,
+                                     g[0].ctt, g[0].ctn, g[0].cnn, Gtt[0], Gtn[0], Gnn[0], g[0].wt, g[0].wn, xtt, xnt, xtn, xnn, z1t, z1n);   // (X^T)
+    good = ok0 && ok1;
+    static_for<0, S::NV>([&](auto II) { dx[II] = (z0t * vt[0][II] + z0n * vn[0][II]) + (z1t * vt[1][II] + z1n * vn[1][II]); });
+  }
+  return good;
+}
+
 // Primal Newton solve of   min_a 0.5 (a-a0)^T M (a-a0) + sum_rows 0.5 D min(0, J a - aref)^2
 // ([3P] engine_solver, Newton, pyramidal cones): exact Hessian M + J^T D_active J with the tree
 // sparsity of M, L^T D L factorisation, exact line search on the piecewise-quadratic 1-D cost.
@@ -896,52 +1006,56 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
     // set at x2 equals the set at x1 (then it is that set's exact minimiser); otherwise the regular iterations go on from x2.
     // PAIR: the lane that owns the toggled slot computes the step, the other one contributes zero; limits: the even lane.
     if constexpr (!BR && !SELF) {
-      const unsigned t_lim = lim_on ^ m_lim, t1 = e1 ^ m_e1, t2 = e2 ^ m_e2, t3 = e3 ^ m_e3, tm = t1 | t2 | t3;
-      const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
 #if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-      if (!lane_done && a == T(1)) gstats().toggles[nl < 3 ? nl : 3][ns < 3 ? ns : 3]++;
+      { const int nl = __builtin_popcount(lim_on ^ m_lim), ns = __builtin_popcount((e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3));
+        if (!lane_done && a == T(1)) gstats().toggles[nl < 3 ? nl : 3][ns < 3 ? ns : 3]++; }
 #endif
-      bool can = !lane_done && a == T(1) && corr != 0 && ((nl == 1 && ns == 0) || (nl == 0 && ns == 1));
+      // groups are dealt to the two lanes of a pair; host builds deal them to two virtual lanes of the one lane (same arithmetic, so the CPU
+      // tests cover it); the one-lane device kernels keep the single-group form (a second group there is two more solves and their registers)
+#if defined(__HIP_DEVICE_COMPILE__)
+      constexpr int CMODE = PAIR ? 1 : 0;
+#else
+      constexpr int CMODE = 2;
+#endif
+      constexpr bool SPLIT = CMODE != 0;
+      // (a second ROUND from x1 against the set found at x2 -- host replay: two-iteration hopper solves 4 284 -> 376 -- was measured on the
+      // device and dropped: a wave repeats the round when ANY lane asks for it and still pays the full iteration when another lane needs
+      // that: + 1 % hopper, + 5 % walker2d, + 8 % half-cheetah.)  corr: 1 = one group (round 2), 2 = two groups.
+      const unsigned t_lim = lim_on ^ m_lim, tm = (e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3);
+      bool can = !lane_done && a == T(1) && corr_valid<SPLIT>(t_lim, tm, corr);
       if (REX_WAVE_ANY(can)) {
-        T Ut[S::NV], Un[S::NV], Ctt = T(0), Ctn = T(0), Cnn = T(0), wt = T(0), wn = T(0), jt1[NC], jn1[NC];
-        static_for<0, S::NV>([&](auto II) { Ut[II] = T(0); Un[II] = T(0); });
-        const bool lim_lane = !PAIR || par == 0u;   // the limit group is replicated: only one lane of a pair may add it
-        static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-          if constexpr (S::limited[j]) {
-            const bool b = ((t_lim >> j) & 1u) && lim_lane;
-            const T sg = ((m_lim >> j) & 1u) ? T(1) : T(-1);            // switched on / off
-            const T xr = C.lsig[j] * qacc[j + 2] - C.laref[j];          // the row at x1
-            Ut[j + 2] = b ? C.lsig[j] : T(0); Ctt += b ? sg * C.lD[j] : T(0); wt += b ? sg * C.lD[j] * xr : T(0); } });
-        for_slots<SLOTS>([&](auto KK) {
-          constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
-          const T mu = P.mu[gg]; const unsigned kk = k + par;
-          jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k];   // J x1 (alpha = 1)
-          const T x0 = jn1[k] + mu * jt1[k] - (C.an[k] + C.at[k]), x1 = jn1[k] - mu * jt1[k] - (C.an[k] - C.at[k]), x2 = jn1[k] - C.an[k];
-          const T d1_ = T(int((m_e1 >> kk) & 1u) - int((e1 >> kk) & 1u)), d2_ = T(int((m_e2 >> kk) & 1u) - int((e2 >> kk) & 1u)),
-                  d3_ = T(int((m_e3 >> kk) & 1u) - int((e3 >> kk) & 1u));   // +1 edge switched on, -1 off, 0 unchanged
-          const T any = ((tm >> kk) & 1u) ? T(1) : T(0);
-          const T Dk = C.D[k];
-          Ctt += Dk * mu * mu * (d1_ + d2_); Ctn += Dk * mu * (d1_ - d2_); Cnn += Dk * (d1_ + d2_ + T(2) * d3_);
-          wt += Dk * mu * (d1_ * x0 - d2_ * x1); wn += Dk * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
-          jt_accum_pre<T, S, b>(Jt[k], Jn[k], any, T(0), Ut);
-          jt_accum_pre<T, S, b>(Jt[k], Jn[k], T(0), any, Un);
-        });
-        T vt[S::NV], vn[S::NV];
-        static_for<0, S::NV>([&](auto II) { vt[II] = Ut[II]; vn[II] = Un[II]; });
-        ldl_solve<T, S>(H, vt); ldl_solve<T, S>(H, vn);
-        T Gtt = T(0), Gtn = T(0), Gnn = T(0);
-        static_for<0, S::NV>([&](auto II) { Gtt += Ut[II] * vt[II]; Gtn += Ut[II] * vn[II]; Gnn += Un[II] * vn[II]; });
-        const T a11 = T(1) + Ctt * Gtt + Ctn * Gtn, a12 = Ctt * Gtn + Ctn * Gnn, a21 = Ctn * Gtt + Cnn * Gtn, a22 = T(1) + Ctn * Gtn + Cnn * Gnn;
-        const T det = a11 * a22 - a12 * a21;
-        bool good = det > T(1e-3);
-        if constexpr (PAIR) good = good && (pair_xchg(good ? 1u : 0u) != 0u);
-        can = can && good;
-        const T idet = can ? rcp_t(det) : T(0);
-        const T zt = can ? (a22 * wt - a12 * wn) * idet : T(0), zn = can ? (a11 * wn - a21 * wt) * idet : T(0);
+        const bool two = SPLIT && corr >= 2 && REX_WAVE_ANY(can && __builtin_popcount(t_lim) + __builtin_popcount(tm) == 2);
+        T jt1[NC], jn1[NC];
+        for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k]; });   // J x1 (alpha = 1)
+        auto build = [&](unsigned vp, CorrGroup<T, S>& g) {
+          unsigned my_lim, my_slots; corr_assign<SPLIT>(t_lim, tm, vp, my_lim, my_slots);
+          if (!can) { my_lim = 0u; my_slots = 0u; }
+          static_for<0, S::NV>([&](auto II) { g.Ut[II] = T(0); g.Un[II] = T(0); });
+          g.ctt = g.ctn = g.cnn = g.wt = g.wn = T(0);
+          static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+            if constexpr (S::limited[j]) {
+              const bool b = (my_lim >> j) & 1u;
+              const T sg = ((m_lim >> j) & 1u) ? T(1) : T(-1);            // switched on / off
+              const T xr = C.lsig[j] * qacc[j + 2] - C.laref[j];          // the row at x1
+              g.Ut[j + 2] = b ? C.lsig[j] : T(0); g.ctt += b ? sg * C.lD[j] : T(0); g.wt += b ? sg * C.lD[j] * xr : T(0); } });
+          for_slots<SLOTS>([&](auto KK) {
+            constexpr int k = KK; constexpr int gg = k / 2; constexpr int b = S::geom_body[gg];
+            const T mu = P.mu[gg]; const unsigned kk = k + par;
+            const T x0 = jn1[k] + mu * jt1[k] - (C.an[k] + C.at[k]), x1 = jn1[k] - mu * jt1[k] - (C.an[k] - C.at[k]), x2 = jn1[k] - C.an[k];
+            const T d1_ = T(int((m_e1 >> kk) & 1u) - int((e1 >> kk) & 1u)), d2_ = T(int((m_e2 >> kk) & 1u) - int((e2 >> kk) & 1u)),
+                    d3_ = T(int((m_e3 >> kk) & 1u) - int((e3 >> kk) & 1u));   // +1 edge switched on, -1 off, 0 unchanged
+            const T any = ((my_slots >> kk) & 1u) ? T(1) : T(0);
+            const T Dk = any * C.D[k];
+            g.ctt += Dk * mu * mu * (d1_ + d2_); g.ctn += Dk * mu * (d1_ - d2_); g.cnn += Dk * (d1_ + d2_ + T(2) * d3_);
+            g.wt += Dk * mu * (d1_ * x0 - d2_ * x1); g.wn += Dk * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
+            jt_accum_pre<T, S, b>(Jt[k], Jn[k], any, T(0), g.Ut);
+            jt_accum_pre<T, S, b>(Jt[k], Jn[k], T(0), any, g.Un);
+          });
+        };
         T dx[S::NV];
-        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = zt * vt[i] + zn * vn[i];
-          if constexpr (PAIR) dx[i] += pair_xchg(dx[i]);
-          qacc[i] -= dx[i]; });
+        const bool good = corr_step<T, S, CMODE>(H, two, par, build, dx);
+        can = can && good;
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = can ? dx[i] : T(0); qacc[i] -= dx[i]; });
         // the set at x2
         unsigned v_lim = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
         static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
@@ -1480,54 +1594,54 @@ REX_HD SolveStats solve_newton_list(const T (&M)[S::NV][S::NV], const T (&qfrc_s
     lane_done = lane_done || exact_step || smax <= stag * (T(1) + amax);
     // ---- one-group correction (see solve_newton): one joint limit or the edges of ONE unit toggled along a full step ----------------------
     {
-      const unsigned t_lim = lim_on ^ m_lim, t1 = e1 ^ m_e1, t2 = e2 ^ m_e2, t3 = e3 ^ m_e3, tm = t1 | t2 | t3;
-      const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
-      bool can = !lane_done && a == T(1) && corr != 0 && m_self == self_on && ((nl == 1 && ns == 0) || (nl == 0 && ns == 1));
+#if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+      { const int nl = __builtin_popcount(lim_on ^ m_lim), ns = __builtin_popcount((e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3));
+        if (!lane_done && a == T(1)) gstats().toggles[nl < 3 ? nl : 3][ns < 3 ? ns : 3]++; }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+      constexpr int CMODE = PAIR ? 1 : 0;
+#else
+      constexpr int CMODE = 2;
+#endif
+      constexpr bool SPLIT = CMODE != 0;
+      const unsigned t_lim = lim_on ^ m_lim, tm = (e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3);
+      bool can = !lane_done && a == T(1) && m_self == self_on && corr_valid<SPLIT>(t_lim, tm, corr);
       if (REX_WAVE_ANY(can)) {
-        T Ut[S::NV], Un[S::NV], Ctt = T(0), Ctn = T(0), Cnn = T(0), wt = T(0), wn = T(0);
-        static_for<0, S::NV>([&](auto II) { Ut[II] = T(0); Un[II] = T(0); });
-        const bool lim_lane = !PAIR || par == 0u;   // the limit group is replicated: only one lane of a pair may add it
-        static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
-          if constexpr (S::limited[j]) {
-            const bool b = ((t_lim >> j) & 1u) && lim_lane && can;
-            const T sg = ((m_lim >> j) & 1u) ? T(1) : T(-1);
-            const T xr = C.lsig[j] * qacc[j + 2] - C.laref[j];
-            Ut[j + 2] = b ? C.lsig[j] : T(0); Ctt += b ? sg * C.lD[j] : T(0); wt += b ? sg * C.lD[j] * xr : T(0); } });
-        {   // the toggled unit: a per-lane index into the column (lanes without one read unit 0 and contribute nothing)
-          const unsigned kb = ns == 1 ? (unsigned)__builtin_ctz(tm | 0x80000000u) : 0u;          // slot bit
-          const bool mine = can && ns == 1 && (!PAIR || (kb & 1u) == par);
+        const bool two = SPLIT && corr >= 2 && REX_WAVE_ANY(can && __builtin_popcount(t_lim) + __builtin_popcount(tm) == 2);
+        auto build = [&](unsigned vp, CorrGroup<T, S>& g) {
+          unsigned my_lim, my_slots; corr_assign<SPLIT>(t_lim, tm, vp, my_lim, my_slots);
+          if (!can) { my_lim = 0u; my_slots = 0u; }
+          static_for<0, S::NV>([&](auto II) { g.Ut[II] = T(0); g.Un[II] = T(0); });
+          g.ctt = g.ctn = g.cnn = g.wt = g.wn = T(0);
+          static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
+            if constexpr (S::limited[j]) {
+              const bool b = (my_lim >> j) & 1u;
+              const T sg = ((m_lim >> j) & 1u) ? T(1) : T(-1);
+              const T xr = C.lsig[j] * qacc[j + 2] - C.laref[j];
+              g.Ut[j + 2] = b ? C.lsig[j] : T(0); g.ctt += b ? sg * C.lD[j] : T(0); g.wt += b ? sg * C.lD[j] * xr : T(0); } });
+          // the toggled unit of this (virtual) lane: a per-lane index into the column (lanes without one read unit 0 and contribute nothing)
+          const bool mine = my_slots != 0u;
+          const unsigned kb = (unsigned)__builtin_ctz(my_slots | 0x80000000u) & 31u;                // slot bit
           const unsigned u = mine ? (PAIR ? kb >> 1 : kb) : 0u;
           const T* q = L.unit(u);
           const T px = q[LM::off(SF_PX)], pz = q[LM::off(SF_PZ)], Dk = q[LM::off(SF_D)], an = q[LM::off(SF_AN)], at = q[LM::off(SF_AT)], mu = q[LM::off(SF_MU)];
-          // (lanes without a toggled unit read unit 0, whose J qacc / J sr words were never written if it is not on the list: select, do not
-          // multiply by zero -- 0 * garbage is NaN)
+          // (J qacc / J sr of unit 0 were never written if it is not on the list: select, do not multiply by zero -- 0 * garbage is NaN)
           const T jt1 = mine ? q[LM::off(SF_LT)] + q[LM::off(SF_LVT)] : T(0), jn1 = mine ? q[LM::off(SF_LN)] + q[LM::off(SF_LVN)] : T(0);   // J x1 (alpha = 1)
           T jt[S::NB], jn[S::NB];
           list_jac<T, S, (1u << S::NB) - 1u>(K, px, pz, anc_of(u), jt, jn);   // (per-lane unit: every body, per-lane weights)
           const T x0 = jn1 + mu * jt1 - (an + at), x1 = jn1 - mu * jt1 - (an - at), x2 = jn1 - an;
-          const T d1_ = T(int((m_e1 >> kb) & 1u) - int((e1 >> kb) & 1u)), d2_ = T(int((m_e2 >> kb) & 1u) - int((e2 >> kb) & 1u)),
-                  d3_ = T(int((m_e3 >> kb) & 1u) - int((e3 >> kb) & 1u));
+          const unsigned ks = mine ? kb : 0u;
+          const T d1_ = T(int((m_e1 >> ks) & 1u) - int((e1 >> ks) & 1u)), d2_ = T(int((m_e2 >> ks) & 1u) - int((e2 >> ks) & 1u)),
+                  d3_ = T(int((m_e3 >> ks) & 1u) - int((e3 >> ks) & 1u));
           const T on = mine ? T(1) : T(0), Dm = mine ? Dk : T(0);
-          Ctt += Dm * mu * mu * (d1_ + d2_); Ctn += Dm * mu * (d1_ - d2_); Cnn += Dm * (d1_ + d2_ + T(2) * d3_);
-          wt += Dm * mu * (d1_ * x0 - d2_ * x1); wn += Dm * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
-          list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, on, T(0), Ut); list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, T(0), on, Un);
-        }
-        T vt[S::NV], vn[S::NV];
-        static_for<0, S::NV>([&](auto II) { vt[II] = Ut[II]; vn[II] = Un[II]; });
-        ldl_solve<T, S>(H, vt); ldl_solve<T, S>(H, vn);
-        T Gtt = T(0), Gtn = T(0), Gnn = T(0);
-        static_for<0, S::NV>([&](auto II) { Gtt += Ut[II] * vt[II]; Gtn += Ut[II] * vn[II]; Gnn += Un[II] * vn[II]; });
-        const T a11 = T(1) + Ctt * Gtt + Ctn * Gtn, a12 = Ctt * Gtn + Ctn * Gnn, a21 = Ctn * Gtt + Cnn * Gtn, a22 = T(1) + Ctn * Gtn + Cnn * Gnn;
-        const T det = a11 * a22 - a12 * a21;
-        bool good = det > T(1e-3);
-        if constexpr (PAIR) good = good && (pair_xchg(good ? 1u : 0u) != 0u);
-        can = can && good;
-        const T idet = can ? rcp_t(det) : T(0);
-        const T zt = can ? (a22 * wt - a12 * wn) * idet : T(0), zn = can ? (a11 * wn - a21 * wt) * idet : T(0);
+          g.ctt += Dm * mu * mu * (d1_ + d2_); g.ctn += Dm * mu * (d1_ - d2_); g.cnn += Dm * (d1_ + d2_ + T(2) * d3_);
+          g.wt += Dm * mu * (d1_ * x0 - d2_ * x1); g.wn += Dm * (d1_ * x0 + d2_ * x1 + T(2) * d3_ * x2);
+          list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, on, T(0), g.Ut); list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, T(0), on, g.Un);
+        };
         T dx[S::NV];
-        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = zt * vt[i] + zn * vn[i];
-          if constexpr (PAIR) dx[i] += pair_xchg(dx[i]);
-          qacc[i] -= dx[i]; });
+        const bool good = corr_step<T, S, CMODE>(H, two, par, build, dx);
+        can = can && good;
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = can ? dx[i] : T(0); qacc[i] -= dx[i]; });
         // the set at x2
         unsigned v_lim = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
         static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
@@ -1560,6 +1674,9 @@ REX_HD SolveStats solve_newton_list(const T (&M)[S::NV][S::NV], const T (&qfrc_s
             ok2 = ok2 && ((((R.mask >> r) & 1u) && jar < T(0)) == (((m_self >> r) & 1u) != 0u));
           }
         }
+#if defined(REX_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+        if (can) { gstats().toggles[3][3]++; if (ok2) gstats().toggles[3][2]++; }   // corrections tried / accepted
+#endif
         lane_done = lane_done || (can && ok2);
         p_lim = can ? m_lim : p_lim; p_e1 = can ? m_e1 : p_e1; p_e2 = can ? m_e2 : p_e2; p_e3 = can ? m_e3 : p_e3; p_self = can ? m_self : p_self;
         ma_dirty = true;

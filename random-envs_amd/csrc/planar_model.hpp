@@ -215,7 +215,7 @@ REX_HD void derive_model(const T* size, PlanarGeom<T, S>& G, T (&nominal_mass)[S
   // that detects an exact step); a solve still running after that gets the safeguarded exact search, up to 3 evaluations
   // per iteration (measured at B = 32768: hopper 0.0945 -> 0.0876 ms, walker2d 0.300 -> 0.265, half-cheetah 0.127 -> 0.118;
   // no solve hit the iteration cap, results unchanged to rounding: tests/test_planar_engine_host.py)
-  sp.ls_max = 3; sp.ls_free = 4; sp.warm = S::RK4 ? 1 : 0; sp.fast = 1; sp.corr = 1;
+  sp.ls_max = 3; sp.ls_free = 4; sp.warm = S::RK4 ? 1 : 0; sp.fast = 1; sp.corr = 2;
 }
 
 // ---------------------------------------------------------------------------------------------------

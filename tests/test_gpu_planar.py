@@ -84,12 +84,15 @@ def test_step_parity_on_rollout_states(torch_mod, kind, lanes):
     env.close()
 
 
-@pytest.mark.parametrize("knobs", [dict(REX_PAIR=0), dict(REX_CORR=0), dict(REX_FAST=0), dict(REX_PAIR=0, REX_CORR=0, REX_LS_FREE=0, REX_LS_MAX=3),
+@pytest.mark.parametrize("knobs", [dict(REX_PAIR=0), dict(REX_CORR=0), dict(REX_CORR=1), dict(REX_FAST=0), dict(REX_FAST=0, REX_PAIR=1),
+                                   dict(REX_FAST=0, REX_PAIR=1, REX_CORR=0), dict(REX_PAIR=0, REX_CORR=0, REX_LS_FREE=0, REX_LS_MAX=3),
                                    dict(REX_ROLLED=1, REX_PAIR=0), dict(REX_ROLLED=1, REX_FAST=0)])
 @pytest.mark.parametrize("kind", ["hopper", "walker2d", "halfcheetah"])
 def test_every_solver_configuration_matches_the_oracle(torch_mod, kind, knobs):
-    """The solver's machinery is switchable at create time (REX_PAIR: two lanes per env, REX_CORR: one-group correction,
-    REX_FAST: feet-only instantiation + qacc_smooth skip, REX_LS_FREE / REX_LS_MAX: line-search schedule, REX_ROLLED (with one lane per env): the
+    """The solver's machinery is switchable at create time (REX_PAIR: two lanes per env, REX_CORR: Woodbury correction off / one group / two
+    groups (the default), REX_FAST: feet-only instantiation + qacc_smooth skip -- with REX_PAIR=1 beside REX_FAST=0 EVERY evaluation of every lane
+    goes through the LIST solver of the two-lanes-per-env kernels (solve_newton_list: the general path of every BASELINE configuration) --,
+    REX_LS_FREE / REX_LS_MAX: line-search schedule, REX_ROLLED (with one lane per env): the
     hopper's 256-register / two-waves-per-SIMD step kernel with the rolled general solver, the default past 65 536 envs -- with REX_FAST=0 every
     evaluation of every lane goes through the rolled solver).  Every
     configuration reaches the same unique minimiser: each one against the oracle, every lane, same tolerances."""
@@ -113,11 +116,13 @@ def test_every_solver_configuration_matches_the_oracle(torch_mod, kind, knobs):
     env.close()
 
 
-@pytest.mark.parametrize("rolled", [0, 1])
-def test_hopper_contact_rich_and_limit_states(torch_mod, rolled):
+@pytest.mark.parametrize("shape", ["pair", "one_lane", "rolled"])
+def test_hopper_contact_rich_and_limit_states(torch_mod, shape):
     """random (not rollout) states: deeper penetrations, joint limits violated, large velocities -- practically every wave leaves the
-    feet-only path, so this is the test of the general solver: the unrolled per-slot one (rolled = 0, the kernels up to 65 536 envs) and the
-    rolled row-list one of the two-waves-per-SIMD kernel (rolled = 1, one lane per env)"""
+    feet-only path, so this is the test of the general solver in its three forms: the LIST solver of the two-lanes-per-env kernels (the default up
+    to 32 768 envs: floor units and capsule-capsule rows in the LDS column, two-group correction), the unrolled per-slot one of the
+    one-lane-per-env kernels, and the rolled row-list one of the two-waves-per-SIMD kernel"""
+    rolled = 1 if shape == "rolled" else 0
     import random_envs_amd as rex
     from parity_util import create_knobs
     from oracle_bindings import oracle_batch_step
@@ -127,8 +132,9 @@ def test_hopper_contact_rich_and_limit_states(torch_mod, rolled):
     q = rng.uniform(-0.4, 0.4, (n, 6)); q[:, 1] = rng.uniform(1.05, 1.4, n); q[:, 5] = rng.uniform(-0.9, 0.9, n)
     v = rng.uniform(-3, 3, (n, 6)); a = rng.uniform(-1.2, 1.2, (n, 3))
     q, v, xi, a = [x.astype(np.float32).astype(np.float64) for x in (q, v, xi, a)]
-    with create_knobs(REX_ROLLED=rolled, REX_PAIR=(0 if rolled else None)):
+    with create_knobs(REX_ROLLED=rolled, REX_PAIR=(None if shape == "pair" else 0)):
         env = rex.make("RandomHopper-v0", batch=n, autoreset=False)
+    assert env.launch_shape()["pair"] == (shape == "pair") and env.launch_shape()["rolled"] == bool(rolled)
     obs, r, dn, qq, vv = _step_from(env, torch_mod, q, v, xi, a)
     ref = oracle_batch_step("hopper", q, v, a, xi)
     vs = 1 + np.abs(ref["qvel"]).max(1)
