@@ -619,26 +619,26 @@ enum { KS_solves = 0, KS_iters = 1, KS_pass1 = 2, KS_pass2 = 3, KS_ls_evals = 4,
 // of two groups except two slots of the same end is covered: limit + slot is 3/4 of what keeps the hopper's slowest waves iterating.
 template <class T, class S>
 struct CorrGroup { T Ut[S::NV], Un[S::NV]; T ctt, ctn, cnn, wt, wn; };   // columns (U_n = 0 for a limit), dC (symmetric 2 x 2), w
-// which toggled rows virtual lane `vp` (0 / 1) takes.  SPLIT: two lanes share the groups by parity; else one lane takes the (single) group.
+// What the toggles (limits t_lim, floor slots tm) allow: `can` one group, or two that the two lanes can share (SPLIT); and which of them
+// virtual lane vp takes: slots by END (slot parity = lane parity), a single limit goes to the lane without a slot, two limits one each.
 template <bool SPLIT>
-REX_HD bool corr_valid(unsigned t_lim, unsigned tm, int corr) {
-  const int nl = __builtin_popcount(t_lim), ns = __builtin_popcount(tm);
-  if (nl + ns == 1) return corr != 0;
-  if (!SPLIT || corr < 2 || nl + ns != 2) return false;
-  return __builtin_popcount(tm & 0x55555555u) <= 1 && __builtin_popcount(tm & 0xAAAAAAAAu) <= 1;
-}
-template <bool SPLIT>
-REX_HD void corr_assign(unsigned t_lim, unsigned tm, unsigned vp, unsigned& my_lim, unsigned& my_slots) {
-  if constexpr (!SPLIT) { my_lim = t_lim; my_slots = tm; }
-  else {
-    const unsigned even = tm & 0x55555555u, odd = tm & 0xAAAAAAAAu;
-    my_slots = vp ? odd : even;
-    const int nl = __builtin_popcount(t_lim);
+struct CorrPlan {
+  unsigned t_lim, even, odd; int nl; bool can, two;
+  REX_HD CorrPlan(unsigned t_lim_, unsigned tm, int corr, bool base) : t_lim(t_lim_), even(SPLIT ? (tm & 0x55555555u) : tm), odd(SPLIT ? (tm & 0xAAAAAAAAu) : 0u) {
+    nl = __builtin_popcount(t_lim);
+    const int ne = __builtin_popcount(even), no = __builtin_popcount(odd), ng = nl + ne + no;
+    two = SPLIT && corr >= 2 && base && ng == 2 && ne <= 1 && no <= 1;
+    can = two || (base && corr != 0 && ng == 1);
+  }
+  REX_HD unsigned my_slots(unsigned vp) const { return !can ? 0u : (SPLIT ? (vp ? odd : even) : even); }
+  REX_HD unsigned my_lim(unsigned vp) const {
+    if (!can) return 0u;
+    if constexpr (!SPLIT) return t_lim;
     const unsigned lane_for_one = (even != 0u && odd == 0u) ? 1u : 0u;          // a single limit: the lane without a slot (lane 0 if neither has one)
     const unsigned lo = t_lim & (0u - t_lim), hi = t_lim & (t_lim - 1u);        // two limits: the lower one to lane 0
-    my_lim = nl == 1 ? (vp == lane_for_one ? t_lim : 0u) : (nl == 2 ? (vp ? hi : lo) : 0u);
+    return nl == 1 ? (vp == lane_for_one ? t_lim : 0u) : (vp ? hi : lo);        // (nl == 0: lo = hi = 0)
   }
-}
+};
 // z of MY group in the coupled system  [I + Cm Gmm, Cm X; Ct X^T, I + Ct Gtt] [zm; zt] = [wm; wt]  (X = Um^T Vt): eliminate the partner's block
 template <class T>
 REX_HD bool corr_pair_solve(T cmtt, T cmtn, T cmnn, T gmtt, T gmtn, T gmnn, T wmt, T wmn,
@@ -664,8 +664,9 @@ REX_HD bool corr_pair_solve(T cmtt, T cmtn, T cmnn, T gmtt, T gmtn, T gmnn, T wm
 // dx = V (I + dC G)^-1 w for the group(s) `build(vp, group)` describes (all-zero group: none).  MODE 0: one group in this lane (the one-lane
 // device kernels); 1: this lane's group + the pair partner's (DPP); 2: both virtual lanes in this lane (host builds: the same arithmetic
 // as mode 1, so the CPU tests hold the two-group algebra to the oracle).  `two` (wave-uniform): some lane has two groups, form the coupling.
+// `use`: this lane (pair) applies the step; dx = 0 where it does not or where a pivot was too small (returns false there).
 template <class T, class S, int MODE, class Build>
-REX_HD bool corr_step(const T (&H)[S::NV][S::NV], bool two, unsigned par, Build&& build, T (&dx)[S::NV]) {
+REX_HD bool corr_step(const T (&H)[S::NV][S::NV], bool two, bool use, unsigned par, Build&& build, T (&dx)[S::NV]) {
   constexpr int NG_ = MODE == 2 ? 2 : 1;
   CorrGroup<T, S> g[NG_];
   T vt[NG_][S::NV], vn[NG_][S::NV], Gtt[NG_], Gtn[NG_], Gnn[NG_];
@@ -680,7 +681,7 @@ REX_HD bool corr_step(const T (&H)[S::NV][S::NV], bool two, unsigned par, Build&
     const T a11 = T(1) + g[0].ctt * Gtt[0] + g[0].ctn * Gtn[0], a12 = g[0].ctt * Gtn[0] + g[0].ctn * Gnn[0];
     const T a21 = g[0].ctn * Gtt[0] + g[0].cnn * Gtn[0], a22 = T(1) + g[0].ctn * Gtn[0] + g[0].cnn * Gnn[0];
     const T det = a11 * a22 - a12 * a21;
-    good = det > T(1e-3);
+    good = use && det > T(1e-3);
     const T idet = good ? rcp_t(det) : T(0);
     const T zt = (a22 * g[0].wt - a12 * g[0].wn) * idet, zn = (a11 * g[0].wn - a21 * g[0].wt) * idet;
     static_for<0, S::NV>([&](auto II) { dx[II] = zt * vt[0][II] + zn * vn[0][II]; });
@@ -702,7 +703,7 @@ REX_HD bool corr_step(const T (&H)[S::NV][S::NV], bool two, unsigned par, Build&
       const T idet = good ? rcp_t(det) : T(0);
       zt = (a22 * g[0].wt - a12 * g[0].wn) * idet; zn = (a11 * g[0].wn - a21 * g[0].wt) * idet;
     }
-    good = good && (pair_xchg(good ? 1u : 0u) != 0u);
+    good = use && good && (pair_xchg(good ? 1u : 0u) != 0u);
     zt = good ? zt : T(0); zn = good ? zn : T(0);
     static_for<0, S::NV>([&](auto II) { constexpr int i = II; const T d = zt * vt[0][i] + zn * vn[0][i]; dx[i] = d + pair_xchg(d); });
   } else {
@@ -713,8 +714,8 @@ REX_HD bool corr_step(const T (&H)[S::NV][S::NV], bool two, unsigned par, Build&
                                      g[1].ctt, g[1].ctn, g[1].cnn, Gtt[1], Gtn[1], Gnn[1], g[1].wt, g[1].wn, xtt, xtn, xnt, xnn, z0t, z0n);
     const bool ok1 = corr_pair_solve(g[1].ctt, g[1].ctn, g[1].cnn, Gtt[1], Gtn[1], Gnn[1], g[1].wt, g[1].wn,
                                      g[0].ctt, g[0].ctn, g[0].cnn, Gtt[0], Gtn[0], Gnn[0], g[0].wt, g[0].wn, xtt, xnt, xtn, xnn, z1t, z1n);   // (X^T)
-    good = ok0 && ok1;
-    static_for<0, S::NV>([&](auto II) { dx[II] = (z0t * vt[0][II] + z0n * vn[0][II]) + (z1t * vt[1][II] + z1n * vn[1][II]); });
+    good = use && ok0 && ok1;
+    static_for<0, S::NV>([&](auto II) { dx[II] = good ? (z0t * vt[0][II] + z0n * vn[0][II]) + (z1t * vt[1][II] + z1n * vn[1][II]) : T(0); });
   }
   return good;
 }
@@ -1021,15 +1022,14 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
       // (a second ROUND from x1 against the set found at x2 -- host replay: two-iteration hopper solves 4 284 -> 376 -- was measured on the
       // device and dropped: a wave repeats the round when ANY lane asks for it and still pays the full iteration when another lane needs
       // that: + 1 % hopper, + 5 % walker2d, + 8 % half-cheetah.)  corr: 1 = one group (round 2), 2 = two groups.
-      const unsigned t_lim = lim_on ^ m_lim, tm = (e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3);
-      bool can = !lane_done && a == T(1) && corr_valid<SPLIT>(t_lim, tm, corr);
+      const CorrPlan<SPLIT> plan(lim_on ^ m_lim, (e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3), corr, !lane_done && a == T(1));
+      bool can = plan.can;
       if (REX_WAVE_ANY(can)) {
-        const bool two = SPLIT && corr >= 2 && REX_WAVE_ANY(can && __builtin_popcount(t_lim) + __builtin_popcount(tm) == 2);
+        const bool two = SPLIT && REX_WAVE_ANY(plan.two);
         T jt1[NC], jn1[NC];
         for_slots<SLOTS>([&](auto KK) { constexpr int k = KK; jt1[k] = lt[k] + lvt[k]; jn1[k] = ln[k] + lvn[k]; });   // J x1 (alpha = 1)
         auto build = [&](unsigned vp, CorrGroup<T, S>& g) {
-          unsigned my_lim, my_slots; corr_assign<SPLIT>(t_lim, tm, vp, my_lim, my_slots);
-          if (!can) { my_lim = 0u; my_slots = 0u; }
+          const unsigned my_lim = plan.my_lim(vp), my_slots = plan.my_slots(vp);
           static_for<0, S::NV>([&](auto II) { g.Ut[II] = T(0); g.Un[II] = T(0); });
           g.ctt = g.ctn = g.cnn = g.wt = g.wn = T(0);
           static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
@@ -1053,9 +1053,8 @@ REX_HD SolveStats solve_newton(const T (&M)[S::NV][S::NV], const T (&qfrc_smooth
           });
         };
         T dx[S::NV];
-        const bool good = corr_step<T, S, CMODE>(H, two, par, build, dx);
-        can = can && good;
-        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = can ? dx[i] : T(0); qacc[i] -= dx[i]; });
+        can = corr_step<T, S, CMODE>(H, two, can, par, build, dx);
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; qacc[i] -= dx[i]; });
         // the set at x2
         unsigned v_lim = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
         static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
@@ -1604,13 +1603,12 @@ REX_HD SolveStats solve_newton_list(const T (&M)[S::NV][S::NV], const T (&qfrc_s
       constexpr int CMODE = 2;
 #endif
       constexpr bool SPLIT = CMODE != 0;
-      const unsigned t_lim = lim_on ^ m_lim, tm = (e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3);
-      bool can = !lane_done && a == T(1) && m_self == self_on && corr_valid<SPLIT>(t_lim, tm, corr);
+      const CorrPlan<SPLIT> plan(lim_on ^ m_lim, (e1 ^ m_e1) | (e2 ^ m_e2) | (e3 ^ m_e3), corr, !lane_done && a == T(1) && m_self == self_on);
+      bool can = plan.can;
       if (REX_WAVE_ANY(can)) {
-        const bool two = SPLIT && corr >= 2 && REX_WAVE_ANY(can && __builtin_popcount(t_lim) + __builtin_popcount(tm) == 2);
+        const bool two = SPLIT && REX_WAVE_ANY(plan.two);
         auto build = [&](unsigned vp, CorrGroup<T, S>& g) {
-          unsigned my_lim, my_slots; corr_assign<SPLIT>(t_lim, tm, vp, my_lim, my_slots);
-          if (!can) { my_lim = 0u; my_slots = 0u; }
+          const unsigned my_lim = plan.my_lim(vp), my_slots = plan.my_slots(vp);
           static_for<0, S::NV>([&](auto II) { g.Ut[II] = T(0); g.Un[II] = T(0); });
           g.ctt = g.ctn = g.cnn = g.wt = g.wn = T(0);
           static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;
@@ -1639,9 +1637,8 @@ REX_HD SolveStats solve_newton_list(const T (&M)[S::NV][S::NV], const T (&qfrc_s
           list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, on, T(0), g.Ut); list_accum<T, S, (1u << S::NB) - 1u>(jt, jn, T(0), on, g.Un);
         };
         T dx[S::NV];
-        const bool good = corr_step<T, S, CMODE>(H, two, par, build, dx);
-        can = can && good;
-        static_for<0, S::NV>([&](auto II) { constexpr int i = II; dx[i] = can ? dx[i] : T(0); qacc[i] -= dx[i]; });
+        can = corr_step<T, S, CMODE>(H, two, can, par, build, dx);
+        static_for<0, S::NV>([&](auto II) { constexpr int i = II; qacc[i] -= dx[i]; });
         // the set at x2
         unsigned v_lim = 0u, v1 = 0u, v2 = 0u, v3 = 0u;
         static_for<1, S::NB>([&](auto JJ) { constexpr int j = JJ;

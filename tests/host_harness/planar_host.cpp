@@ -112,3 +112,4 @@ extern "C" int ph_walker_compact_check(const double* size, const double* nominal
   *max_err = e;
   return worst;
 }
+

@@ -199,3 +199,4 @@ def test_line_search_schedule_does_not_change_the_solution(kind):
             assert e.max() < 1e-6 and cap.sum() == 0, (ls_max, ls_free, e.max(), cap.sum())
     finally:
         set_line_search(-1, -1)
+
