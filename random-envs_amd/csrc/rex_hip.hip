@@ -869,7 +869,8 @@ struct rex_env {
   int full_dim = 0;                 // rows of the full xi block (dims.task_dim = rows exposed as the task)
   float* d_scratch = nullptr;   // MAX_XI floats
   float* d_chol = nullptr;      // MAX_XI*MAX_XI floats (fullgaussian Cholesky factor)
-  int lanes = 32;               // lanes per workgroup, fixed at create time (lanes_for)
+  int lanes = 32;               // lanes per workgroup of the one-lane-per-env launches, fixed at create time (lanes_for)
+  int pair_lanes = 64;          // lanes per workgroup of the two-lanes-per-env planar step (pair_lanes_for): narrower waves while they all still get a SIMD
   int pair = 1;                 // planar chains: two lanes per env up to 32 envs x SIMDs, one lane per env past that (REX_PAIR overrides)
   int hum_pair = 1;             // humanoid step: two lanes per env (humanoid_pair_step_kernel; REX_HUM_PAIR=0: one env per lane)
   int rolled = 0;               // hopper, one lane per env: the 256-register step kernel (rolled general solver, two waves per SIMD); REX_ROLLED overrides
@@ -971,6 +972,20 @@ static int lanes_for(long long B, int simds) {
   const char* e = knob("REX_LANES");
   if (e && atoi(e) > 0) return atoi(e);
   return B > 32ll * simds ? 64 : 32;
+}
+// Two lanes per env: a step launch costs ONE wave's latency while every wave has a SIMD to itself, and a wave pays for the slowest of its envs in
+// every Newton pass -- so a batch that leaves SIMDs idle is spread over them in narrower waves (16 384 envs: 32-lane blocks = 16 envs per wave,
+// 8 192: 16 lanes, <= 4 096: 8 lanes = 4 envs per wave): fewer envs to wait for per pass, and fewer waves that one fallen env sends through the
+// general solver (host replay of the half-cheetah: 9.4 -> 8.1 -> 6.9 Newton passes per wave-step at 32 / 16 / 8 envs per wave).  Measured (step kernel,
+// 64-lane blocks -> narrower): walker2d 16 384 envs 0.1910 -> 0.1828 ms, 8 192 envs 0.1763 -> 0.1650; half-cheetah 0.1011 -> 0.0975 and 0.0975 -> 0.0937;
+// the hopper gains nothing at 32 lanes and loses 4 % at 16; 8-lane blocks are 2.2 - 2.5x slower for every chain (gpurun_out/r4u): floors 32 / 16 / 16.
+static int pair_lanes_for(int kind, long long B, int simds) {
+  const char* e = knob("REX_LANES");
+  if (e && atoi(e) > 0) return atoi(e);
+  const int floor_ = kind == REX_HOPPER ? 32 : 16;
+  int L = 64;
+  while (L > floor_ && (4 * B + L - 1) / L <= (long long)simds) L /= 2;   // halve while the halved blocks still number <= SIMDs
+  return L;
 }
 // dynamic LDS of the humanoid kernels: one dual-PGS column (hum::DUAL_WORDS floats) per lane
 // (read once in rex_create and cached in the handle: grid, block and dynamic-LDS size always agree)
@@ -1096,6 +1111,8 @@ static int create_body(rex_env* h, int env_kind, int variant, int64_t batch, int
   if (knob("REX_FAST")) h->sp.fast = atoi(knob("REX_FAST"));
   // launch shape by batch (lanes_for above has the measurements); rex_set_launch_shape overrides it per handle
   h->pair = batch <= 32ll * simds ? 1 : 0;
+  h->pair_lanes = pair_lanes_for(env_kind, batch, simds);
+  if (h->pair_lanes < 8 || h->pair_lanes > 64 || (h->pair_lanes & (h->pair_lanes - 1))) return set_err(REX_ERR_ARG, "REX_LANES must be 8, 16, 32 or 64 (got %d)", h->pair_lanes);
   h->rolled = (env_kind == REX_HOPPER && batch > 64ll * simds) ? 1 : 0;
   if (knob("REX_PAIR")) h->pair = atoi(knob("REX_PAIR")) ? 1 : 0;
   if (knob("REX_ROLLED")) h->rolled = (env_kind == REX_HOPPER && atoi(knob("REX_ROLLED"))) ? 1 : 0;
@@ -1266,9 +1283,9 @@ template <class S>
 static void launch_planar_step(rex_env* h, const DevState& dev, const StepFlags& flags, const PlanarGeom<float, S>& geom, const float* action,
                                float* obs_out, float* reward_out, uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out,
                                int fused, int resample, hipStream_t st) {
-  if (h->pair) {   // 2 B lanes in 64-lane blocks: 32 envs per wave
-    const unsigned blocks = (unsigned)((2 * h->B + 63) / 64);
-    hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(64), 0, st, dev, flags, geom, h->sp, action, obs_out, reward_out,
+  if (h->pair) {   // 2 B lanes in blocks of pair_lanes: 32 envs per wave at 32 768 envs, fewer while SIMDs would idle (pair_lanes_for)
+    const unsigned L = (unsigned)h->pair_lanes, blocks = (unsigned)((2 * h->B + L - 1) / L);
+    hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(L), 0, st, dev, flags, geom, h->sp, action, obs_out, reward_out,
                        done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);
   } else {
     if constexpr (S::KIND == 1) {
@@ -1517,14 +1534,14 @@ extern "C" int rex_get_counters(rex_t* h, int64_t* out) {
 extern "C" int rex_get_launch_shape(const rex_t* h, int32_t* out) {
   if (!h || !out) return set_err(REX_ERR_ARG, "rex_get_launch_shape: null argument");
   const bool planar = h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || h->kind == REX_WALKER2D;
-  out[0] = h->lanes; out[1] = (planar && h->pair) ? 1 : 0; out[2] = (h->kind == REX_HOPPER && !h->pair && h->rolled) ? 1 : 0;
+  out[0] = (planar && h->pair) ? h->pair_lanes : h->lanes; out[1] = (planar && h->pair) ? 1 : 0; out[2] = (h->kind == REX_HOPPER && !h->pair && h->rolled) ? 1 : 0;
   out[3] = (h->kind == REX_HUMANOID && h->hum_pair) ? 1 : 0;
   return REX_OK;
 }
 extern "C" int rex_set_launch_shape(rex_t* h, const int32_t* shape) {
   if (!h || !shape) return set_err(REX_ERR_ARG, "rex_set_launch_shape: null argument");
   const bool planar = h->kind == REX_HOPPER || h->kind == REX_HALFCHEETAH || h->kind == REX_WALKER2D;
-  int lanes = shape[0] < 0 ? h->lanes : shape[0];
+  int lanes = shape[0] < 0 ? ((planar && h->pair) ? h->pair_lanes : h->lanes) : shape[0];
   int pair = shape[1] < 0 ? h->pair : (shape[1] ? 1 : 0), rolled = shape[2] < 0 ? h->rolled : (shape[2] ? 1 : 0);
   int hum_pair = shape[3] < 0 ? h->hum_pair : (shape[3] ? 1 : 0);
   if (lanes < 8 || lanes > 64 || (lanes & (lanes - 1))) return set_err(REX_ERR_ARG, "rex_set_launch_shape: lanes must be 8, 16, 32 or 64 (got %d)", lanes);
@@ -1532,7 +1549,8 @@ extern "C" int rex_set_launch_shape(rex_t* h, const int32_t* shape) {
   if (shape[2] > 0 && h->kind != REX_HOPPER) return set_err(REX_ERR_ARG, "rex_set_launch_shape: the rolled kernel exists for the hopper only");
   if (shape[3] > 0 && h->kind != REX_HUMANOID) return set_err(REX_ERR_ARG, "rex_set_launch_shape: hum_pair is a shape of the humanoid");
   if (pair && rolled) return set_err(REX_ERR_ARG, "rex_set_launch_shape: the rolled kernel is a one-lane-per-env kernel (pair and rolled exclude each other)");
-  h->lanes = lanes; h->pair = pair; h->rolled = rolled; h->hum_pair = hum_pair;
+  if (shape[0] >= 0) { h->lanes = lanes; h->pair_lanes = lanes; }
+  h->pair = pair; h->rolled = rolled; h->hum_pair = hum_pair;
   return REX_OK;
 }
 extern "C" int rex_enable_timing(rex_t* h, int enable) {

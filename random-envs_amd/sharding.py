@@ -34,7 +34,13 @@ def shape_for_batch(kind, batch, simds=1024):
     """The launch shape rex_create picks for `batch` envs of `kind` on a GPU with `simds` SIMDs (MI355X: 1 024): the rule of
     rex_hip.hip::create_body restated for the host (tests/test_gpu_api.py::test_launch_shape_follows_the_batch holds the two together)."""
     planar = kind in ("hopper", "halfcheetah", "walker2d")
-    return dict(lanes=64 if batch > 32 * simds else 32, pair=bool(planar and batch <= 32 * simds),
+    pair = bool(planar and batch <= 32 * simds)
+    lanes = 64 if batch > 32 * simds else 32
+    if pair:   # two lanes per env: blocks halve while the halved blocks still number <= SIMDs, down to 32 (hopper) / 16 lanes (pair_lanes_for)
+        lanes, floor_ = 64, (32 if kind == "hopper" else 16)
+        while lanes > floor_ and (4 * batch + lanes - 1) // lanes <= simds:
+            lanes //= 2
+    return dict(lanes=lanes, pair=pair,
                 rolled=bool(kind == "hopper" and batch > 64 * simds), hum_pair=(kind == "humanoid"))
 
 
