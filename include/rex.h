@@ -181,7 +181,8 @@ int64_t rex_step_count(const rex_t* h);
 int rex_get_counters(rex_t* h, int64_t* out);
 
 /* the launch shape rex_create picked for this handle from its batch and the GPU's SIMD count (rex_set_launch_shape and,
- * under REX_ALLOW_TUNING=1, the REX_LANES / REX_PAIR / REX_ROLLED / REX_HUM_PAIR knobs override): out[0] lanes per workgroup of the step launch (two lanes per env: 64 at 32 768 envs, 32 / 16 while narrower waves still all get a SIMD; one lane
+ * under REX_ALLOW_TUNING=1, the REX_LANES / REX_PAIR / REX_ROLLED / REX_HUM_PAIR knobs override): out[0] lanes per workgroup of the step launch (two lanes per env: 64; 32 / 16 for a
+ * walker2d / half-cheetah batch of 8 .. 16 envs per SIMD, where narrower waves still all get a SIMD; one lane
  * per env: 32, 64 past 32 768 envs), out[1] 1 = the planar step runs
  * two lanes per env, out[2] 1 = hopper step on the 256-register kernel with the rolled general solver (two waves per SIMD), out[3] 1 = the
  * humanoid step runs two lanes per env.  No reference counterpart (the reference steps one MjSim on one core); bench.py names the launched

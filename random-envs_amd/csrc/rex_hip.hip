@@ -57,6 +57,7 @@ extern "C" int rex_debug_ktime(unsigned long long* out) {   // diagnostic build 
 // B = 32 768 is the SLOWEST wave's, not the average)
 namespace rex { __device__ unsigned long long g_wavetime[8192]; __device__ unsigned long long g_waveinfo[8192][8]; __device__ unsigned long long g_wavehum[1024][16];
                 __device__ unsigned long long g_wavephase[8192][4];
+                __device__ unsigned long long g_waveplace[8192][4];   // 100 MHz clock at entry and exit, HW_ID, XCC_ID: where and when each wave ran
                 }
 #endif
 #if defined(REX_WAVETIME) || defined(REX_PHASES)
@@ -69,6 +70,8 @@ extern "C" int rex_debug_evalphase(unsigned long long* out, int n) {
 // g_wavephase: planar step kernel, cycles entry -> state loaded -> substeps done -> outputs stored -> fused reset done
 extern "C" int rex_debug_wavephase(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavephase), sizeof(unsigned long long) * 4 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1; }
+extern "C" int rex_debug_waveplace(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_waveplace), sizeof(unsigned long long) * 4 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1; }
 extern "C" int rex_debug_wavehum(unsigned long long* out) {   // humanoid: per-wave phase accumulators of the last launch (-DREX_KTIME -DREX_WAVETIME)
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rex::g_wavehum), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -1; }
 extern "C" int rex_debug_waveinfo(unsigned long long* out, int n) {   // n waves x 8 counters, then zeroed
@@ -334,6 +337,7 @@ planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
                                                          DRParams dr, int fused_reset, int resample) {
 #if defined(REX_WAVETIME)
   const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;   // (both lanes of a pair leave together: i is the same)
@@ -433,6 +437,8 @@ planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
 #if defined(REX_WAVETIME)
   if ((threadIdx.x & 63) == 0) { g_waveinfo[blockIdx.x & 8191][1] += __builtin_amdgcn_s_memtime() - tr0; }   // slot 1 ("iters", unused): cycles in the fused reset
   if ((threadIdx.x & 63) == 0) { unsigned long long* ph = g_wavephase[blockIdx.x & 8191]; ph[0] = tk0 - tp0; ph[1] = tk1 - tk0; ph[2] = tr0 - tk1; ph[3] = __builtin_amdgcn_s_memtime() - tr0; }
+  if ((threadIdx.x & 63) == 0) { unsigned long long* pl = g_waveplace[blockIdx.x & 8191]; pl[0] = tw0; pl[1] = __builtin_amdgcn_s_memrealtime();
+    pl[2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); pl[3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20); }   // HW_REG_HW_ID, HW_REG_XCC_ID
 #endif
 }
 
@@ -974,17 +980,19 @@ static int lanes_for(long long B, int simds) {
   return B > 32ll * simds ? 64 : 32;
 }
 // Two lanes per env: a step launch costs ONE wave's latency while every wave has a SIMD to itself, and a wave pays for the slowest of its envs in
-// every Newton pass -- so a batch that leaves SIMDs idle is spread over them in narrower waves (16 384 envs: 32-lane blocks = 16 envs per wave,
-// 8 192: 16 lanes, <= 4 096: 8 lanes = 4 envs per wave): fewer envs to wait for per pass, and fewer waves that one fallen env sends through the
-// general solver (host replay of the half-cheetah: 9.4 -> 8.1 -> 6.9 Newton passes per wave-step at 32 / 16 / 8 envs per wave).  Measured (step kernel,
-// 64-lane blocks -> narrower): walker2d 16 384 envs 0.1910 -> 0.1828 ms, 8 192 envs 0.1763 -> 0.1650; half-cheetah 0.1011 -> 0.0975 and 0.0975 -> 0.0937;
-// the hopper gains nothing at 32 lanes and loses 4 % at 16; 8-lane blocks are 2.2 - 2.5x slower for every chain (gpurun_out/r4u): floors 32 / 16 / 16.
+// every Newton pass -- so a walker2d / half-cheetah batch that leaves SIMDs idle is spread over them in narrower waves (16 384 envs: 32-lane
+// blocks = 16 envs per wave, 8 192: 16 lanes): fewer envs to wait for per pass (walker2d: 26.5 -> 21.0 passes per wave-step at 16 lanes).  Two
+// limits, both measured (profiles/HISTORY.md, round 4; profiles/waveplace_probe.py):
+//  - a CU with fewer than 64 ACTIVE lanes on it runs the same instruction stream slower (walker2d, cycles per Newton pass: 12.5 k with one 64-lane
+//    wave on the CU, 13.1 k with four 16-lane waves, 14.2 k with one 32-lane wave, 18.8 k with two 16-lane waves -- same clock, same pass
+//    counts, one wave per SIMD in every case), so below 8 envs per SIMD (8 192 envs) the blocks stay 64 lanes wide;
+//  - the hopper's waves gain nothing from being narrow (its slowest wave is set by the feet-only passes every env runs): always 64 lanes.
 static int pair_lanes_for(int kind, long long B, int simds) {
   const char* e = knob("REX_LANES");
   if (e && atoi(e) > 0) return atoi(e);
-  const int floor_ = kind == REX_HOPPER ? 32 : 16;
+  if (kind == REX_HOPPER || B < 8ll * simds) return 64;
   int L = 64;
-  while (L > floor_ && (4 * B + L - 1) / L <= (long long)simds) L /= 2;   // halve while the halved blocks still number <= SIMDs
+  while (L > 16 && (4 * B + L - 1) / L <= (long long)simds) L /= 2;   // halve while the halved blocks still number <= SIMDs
   return L;
 }
 // dynamic LDS of the humanoid kernels: one dual-PGS column (hum::DUAL_WORDS floats) per lane
@@ -1283,7 +1291,7 @@ template <class S>
 static void launch_planar_step(rex_env* h, const DevState& dev, const StepFlags& flags, const PlanarGeom<float, S>& geom, const float* action,
                                float* obs_out, float* reward_out, uint8_t* done_out, uint8_t* truncated_out, float* terminal_obs_out,
                                int fused, int resample, hipStream_t st) {
-  if (h->pair) {   // 2 B lanes in blocks of pair_lanes: 32 envs per wave at 32 768 envs, fewer while SIMDs would idle (pair_lanes_for)
+  if (h->pair) {   // 2 B lanes in blocks of pair_lanes: 32 envs per wave, fewer for a walker2d / half-cheetah batch of 8 192 .. 16 384 (pair_lanes_for)
     const unsigned L = (unsigned)h->pair_lanes, blocks = (unsigned)((2 * h->B + L - 1) / L);
     hipLaunchKernelGGL((planar_step_kernel<S, true>), dim3(blocks), dim3(L), 0, st, dev, flags, geom, h->sp, action, obs_out, reward_out,
                        done_out, truncated_out, terminal_obs_out, h->dr, fused, resample);

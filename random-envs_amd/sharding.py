@@ -36,9 +36,9 @@ def shape_for_batch(kind, batch, simds=1024):
     planar = kind in ("hopper", "halfcheetah", "walker2d")
     pair = bool(planar and batch <= 32 * simds)
     lanes = 64 if batch > 32 * simds else 32
-    if pair:   # two lanes per env: blocks halve while the halved blocks still number <= SIMDs, down to 32 (hopper) / 16 lanes (pair_lanes_for)
-        lanes, floor_ = 64, (32 if kind == "hopper" else 16)
-        while lanes > floor_ and (4 * batch + lanes - 1) // lanes <= simds:
+    if pair:   # two lanes per env: 64-lane blocks; walker2d / half-cheetah batches of >= 8 envs per SIMD halve them while the halved
+        lanes = 64   # blocks still number <= SIMDs, down to 16 lanes (pair_lanes_for)
+        while kind != "hopper" and batch >= 8 * simds and lanes > 16 and (4 * batch + lanes - 1) // lanes <= simds:
             lanes //= 2
     return dict(lanes=lanes, pair=pair,
                 rolled=bool(kind == "hopper" and batch > 64 * simds), hum_pair=(kind == "humanoid"))

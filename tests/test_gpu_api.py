@@ -165,8 +165,9 @@ def test_launch_shape_follows_the_batch(torch_mod):
     from parity_util import create_knobs
     simds = 4 * torch_mod.cuda.get_device_properties(0).multi_processor_count
     for eid, hopper in (("RandomHopper-v0", True), ("RandomWalker2d-v0", False), ("RandomHalfCheetah-v0", False)):
-        fl = 32 if hopper else 16     # narrowest block of the two-lanes-per-env step (pair_lanes_for)
-        for B, want in ((1, (fl, True, False)), (8 * simds, (fl, True, False)), (16 * simds, (32, True, False)), (16 * simds + 1, (64, True, False)),
+        n16, n32 = (64, 64) if hopper else (16, 32)     # walker2d / half-cheetah: narrower blocks from 8 envs per SIMD up while they all get a SIMD (pair_lanes_for)
+        for B, want in ((1, (64, True, False)), (8 * simds - 1, (64, True, False)), (8 * simds, (n16, True, False)), (8 * simds + 1, (n32, True, False)),
+                        (16 * simds, (n32, True, False)), (16 * simds + 1, (64, True, False)),
                         (32 * simds, (64, True, False)), (32 * simds + 1, (64, False, False)),
                         (64 * simds, (64, False, False)), (64 * simds + 1, (64, False, hopper))):
             env = rex.make(eid, batch=B, autoreset=False)
@@ -211,7 +212,7 @@ def test_stray_knobs_are_refused_and_shapes_are_pinned_through_the_abi(torch_mod
         with pytest.raises(_native.RexError, match="REX_TUNING"):
             rex.make("RandomHumanoid-v0", batch=64, autoreset=False)
     env = rex.make("RandomHopper-v0", batch=256, autoreset=False)
-    assert env.launch_shape() == dict(lanes=32, pair=True, rolled=False, hum_pair=False)      # (hopper, 256 envs: the 32-lane floor)
+    assert env.launch_shape() == dict(lanes=64, pair=True, rolled=False, hum_pair=False)
     assert env.set_launch_shape(lanes=64, pair=False) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
     assert env.set_launch_shape(rolled=True) == dict(lanes=64, pair=False, rolled=True, hum_pair=False)
     assert env.set_launch_shape() == dict(lanes=64, pair=False, rolled=True, hum_pair=False)       # all -1: nothing changes

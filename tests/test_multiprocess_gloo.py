@@ -96,8 +96,9 @@ def test_shape_for_batch_restates_rex_create():
     from random_envs_amd import sharding
     f = sharding.shape_for_batch
     assert f("hopper", 32768) == dict(lanes=64, pair=True, rolled=False, hum_pair=False)
-    assert f("hopper", 16384) == dict(lanes=32, pair=True, rolled=False, hum_pair=False) and f("hopper", 4096)["lanes"] == 32
-    assert f("walker2d", 16384)["lanes"] == 32 and f("walker2d", 8192)["lanes"] == 16 and f("halfcheetah", 1)["lanes"] == 16
+    assert f("hopper", 16384) == dict(lanes=64, pair=True, rolled=False, hum_pair=False) and f("hopper", 8192)["lanes"] == 64
+    assert f("walker2d", 16384)["lanes"] == 32 and f("walker2d", 8192)["lanes"] == 16 and f("halfcheetah", 8193)["lanes"] == 32
+    assert f("walker2d", 8191)["lanes"] == 64 and f("halfcheetah", 1)["lanes"] == 64
     assert f("hopper", 32769) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
     assert f("hopper", 65537) == dict(lanes=64, pair=False, rolled=True, hum_pair=False)
     assert f("walker2d", 65537) == dict(lanes=64, pair=False, rolled=False, hum_pair=False)
