@@ -1,7 +1,7 @@
 """Diagnostic: where a humanoid forward evaluation spends its time (build with -DREX_KTIME: s_memtime deltas summed in
 registers per lane, wave maximum flushed once per kernel).  Steady-state batch: episodes end (z < 1) and restart all the time."""
 import os, sys, ctypes, time
-os.environ["REX_LIB"] = "librex_hip_ktime.so"
+os.environ.setdefault("REX_LIB", "librex_hip_ktime.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, random_envs_amd as rex
 from random_envs_amd import _native

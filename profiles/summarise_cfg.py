@@ -57,7 +57,7 @@ try:
 except Exception:
     rec = {}
 if traffic is not None:
-    rec[key] = {"kernel": kname, "batch": int(line["config"]["global_batch"]) // max(int(line["n_gpus"]), 1), "bytes_per_launch": traffic, "source_digest": bench.source_digest(),
+    rec[key] = {"kernel": kname, "batch": int(line["config"]["global_batch"]) // max(int(line["n_gpus"]), 1), "bytes_per_launch": traffic, "source_digest": (os.environ.get("REX_SOURCE_DIGEST") or bench.source_digest()),
                 "source": "profiles/%s_pmc_summary.json (FETCH_SIZE*1024*2 + WRITE_SIZE*1024)" % tag}
     json.dump(rec, open(tp, "w"), indent=1)
 cp = os.path.join(ROOT, "profiles", tag.split("_")[0] + "_configs.json")
@@ -69,7 +69,7 @@ alg = line["roofline"]["algorithmic_bytes_per_launch"]
 cfgs[key] = {"bench_line": line, "rocprof_kernel_stats": kstats, "hbm_bytes_per_launch_pmc": traffic,
              "traffic_over_algorithmic": (traffic / alg) if traffic else None,
              "roofline_frac_from_rocprof": (alg / (kstats["avg_ns"] * 1e-9) / 1e9 / bench.HBM_PEAK_GBS) if kstats else None,
-             "files": ["profiles/%s_kernel_stats.csv" % tag, "profiles/%s_pmc_summary.json" % tag], "source_digest": bench.source_digest()}
+             "files": ["profiles/%s_kernel_stats.csv" % tag, "profiles/%s_pmc_summary.json" % tag], "source_digest": (os.environ.get("REX_SOURCE_DIGEST") or bench.source_digest())}
 json.dump(cfgs, open(cp, "w"), indent=1)
 print(key, "value %.2f M env-steps/s, kernel (events) %.4f ms, rocprof avg %s ms over %s launches, traffic %s MB = %sx algorithmic" % (
     line["value"] / 1e6, line["roofline"]["kernel_avg_ms"], kstats and "%.4f" % (kstats["avg_ns"] * 1e-6), kstats and kstats["calls"],
