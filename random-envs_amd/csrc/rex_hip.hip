@@ -339,7 +339,14 @@ planar_step_kernel(DevState s, StepFlags fl, PlanarGeom<float, S> ugeom,
   const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
   const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);   // 32-bit lane offset + uniform (SGPR) row bases
+  // Narrow blocks (pair_lanes_for: 32 / 16 lanes) touch 64 / 32 bytes of every SoA row, so 2 / 4 neighbouring blocks share each 128-byte line.  Blocks are
+  // dealt round-robin over the 8 XCDs (b and b + 8 share one: MI355X_MICROARCH.md, workgroup dispatch), each with its own L2: in launch order
+  // the sharers sit on different XCDs and every line is fetched 2 / 4 times (C4: 4.4x the algorithmic bytes).  Transposed, block b works on the
+  // env group (b % 8) * (blocks / 8) + b / 8: neighbours in memory are neighbours on one XCD.  The groups themselves -- which envs share a wave --
+  // do not change, so neither does any result.
+  unsigned blk = blockIdx.x;
+  if constexpr (PAIR) { if (blockDim.x < 64u && (gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3); }
+  const unsigned i = (blk * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);   // 32-bit lane offset + uniform (SGPR) row bases
   if (i >= s.B) return;   // (both lanes of a pair leave together: i is the same)
   const long long B = s.B;
   float q[S::NV], v[S::NV], ctrl[S::NU], xi[S::NXI];
