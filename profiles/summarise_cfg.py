@@ -66,6 +66,13 @@ try:
 except Exception:
     cfgs = {}
 alg = line["roofline"]["algorithmic_bytes_per_launch"]
+if traffic is not None and line["roofline"].get("traffic") != traffic:
+    # the bench line of a collection is printed BEFORE its own PMC passes are summarised: on the box it read the previous collection's
+    # hbm_traffic.json (other kernel sources: null, or another box's figure).  Record the line as bench.py prints it against THIS collection's file.
+    line["roofline"]["traffic_as_printed"] = line["roofline"].get("traffic")
+    line["roofline"]["traffic"] = traffic
+    line["roofline"].pop("traffic_note", None)
+    line["roofline"]["traffic_source"] = "profiles/hbm_traffic.json as written by this collection's PMC passes (summarise_cfg.py)"
 cfgs[key] = {"bench_line": line, "rocprof_kernel_stats": kstats, "hbm_bytes_per_launch_pmc": traffic,
              "traffic_over_algorithmic": (traffic / alg) if traffic else None,
              "roofline_frac_from_rocprof": (alg / (kstats["avg_ns"] * 1e-9) / 1e9 / bench.HBM_PEAK_GBS) if kstats else None,
