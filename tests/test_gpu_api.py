@@ -258,3 +258,35 @@ def test_pinned_shards_reproduce_a_single_gpu_batch_past_the_pair_limit(torch_mo
         assert torch.equal(o[off:off + n], o1) and torch.equal(r[off:off + n], r1) and torch.equal(d[off:off + n], d1)
     o, o2 = full[0][0][off:off + n], free[0][0]
     assert not torch.equal(o, o2) and (o - o2).abs().max() < 1e-3   # another kernel: equal to rounding after one step, not bit for bit
+
+
+def test_narrow_blocks_in_xcd_order_cover_every_env(torch_mod):
+    """The 32- / 16-lane two-lanes-per-env blocks take their env group in XCD-transposed order (planar_step_kernel: block b works on group
+    (b % 8) * (blocks / 8) + b / 8 when the block count is a multiple of 8).  Every env must be stepped exactly once -- also with a ragged last
+    group, also when the block count is no multiple of 8 and the order stays the launch order -- and agree with the same envs on 64-lane blocks
+    to fp32 rounding (another grouping of envs into waves: not bit for bit)."""
+    import random_envs_amd as rex
+    torch = torch_mod
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    for eid, nact in (("RandomWalker2d-v0", 6), ("RandomHalfCheetah-v0", 6)):
+        # 16 * 8 m - 5 envs: 32-lane blocks, 8 m of them, the last one ragged;  8 * simds: 16-lane blocks;  8 * simds + 9: 32-lane blocks, count odd
+        for B, lanes in ((16 * (simds * 3 // 4) - 5, 32), (8 * simds, 16), (8 * simds + 9, 32)):
+            g = torch.Generator().manual_seed(11)
+            acts = (torch.rand(2, B, nact, generator=g) * 2 - 1).cuda()
+            outs = []
+            for pin in (False, True):
+                env = rex.make(eid, batch=B, seed=5)
+                if pin:
+                    env.set_launch_shape(lanes=64)
+                assert env.launch_shape()["pair"] and env.launch_shape()["lanes"] == (64 if pin else lanes), (eid, B, env.launch_shape())
+                env.reset()
+                o = [env.step(acts[t])[0].clone() for t in range(2)]
+                q, v = env.get_state()
+                assert env.counters()["nonfinite"] == 0
+                outs.append((o, q.clone(), v.clone()))
+                env.close()
+            (o_n, q_n, v_n), (o_w, q_w, v_w) = outs
+            assert torch.isfinite(o_n[1]).all()
+            assert (o_n[0] - o_w[0]).abs().max() < 2e-3 and (q_n - q_w).abs().max() < 2e-3, (eid, B, float((o_n[0] - o_w[0]).abs().max()))
+            assert (v_n - v_w).abs().max() < 2e-2, (eid, B, float((v_n - v_w).abs().max()))   # (an env left out of a step would be off by g * dt = 0.08)
+            assert not torch.equal(q_n[-8:], torch.zeros_like(q_n[-8:]))      # (the ragged tail was stepped too: its state left the reset noise)
